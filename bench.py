@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Headline benchmark: ResNet-50 synthetic 224×224 training throughput (images/sec, whole job).
+
+Contract (see the task statement): ``python bench.py --gpus N --steps K --warmup W``; for N>1
+the driver launches one rank per GPU with ``torch.distributed.run`` and this script reads
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment.  W untimed warm-up steps, then
+exactly K timed steps bracketed by barrier + ``torch.cuda.synchronize()``; the time is the MAX
+over ranks and rank 0 prints ONE JSON line.
+
+Metric and configuration follow BASELINE.json: ResNet-50, bf16, synthetic data, batch 256 per
+GPU (weak scaling), SGD momentum 0.9 with lr 0.001×N as in the reference
+(``HorovodPytorch/src/imagenet_pytorch_horovod.py:333``), random-init weights.  Every timed
+step does the full work of the reference's hot loop (``:210-218``): batch fetch, zero_grad,
+forward, loss, backward with overlapped gradient all-reduce, optimizer step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import distributeddeeplearning_amd.torch as hvd  # noqa: E402
+from distributeddeeplearning_amd.data.synthetic import DeviceSyntheticLoader  # noqa: E402
+from distributeddeeplearning_amd.models import build_model  # noqa: E402
+from distributeddeeplearning_amd.ops import functional as ops  # noqa: E402
+from distributeddeeplearning_amd.optim import FusedLARS, FusedSGD  # noqa: E402
+
+# Stock PyTorch-ROCm (MIOpen, bf16 autocast, channels_last) ResNet-50 batch 256 on one MI355X,
+# measured with benchmarks/stock_pytorch.py — see BASELINE.md.  The reference itself
+# publishes no number.
+STOCK_PYTORCH_IMG_PER_S_1GPU = None
+
+
+def _read_baseline():
+    path = os.path.join(ROOT, "BASELINE_MEASURED.json")
+    try:
+        with open(path) as fh:
+            return float(json.load(fh)["stock_pytorch_resnet50_bf16_b256_img_per_s_1gpu"])
+    except Exception:
+        return STOCK_PYTORCH_IMG_PER_S_1GPU
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "lars"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--device", default=None, help="cuda|cpu (default: cuda when available)")
+    ap.add_argument("--image", type=int, default=224)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    use_cuda = (args.device or ("cuda" if torch.cuda.is_available() else "cpu")) == "cuda"
+    hvd.init()
+    world, rank = hvd.size(), hvd.rank()
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE is %d; using WORLD_SIZE" % (args.gpus, world),
+              file=sys.stderr)
+    device = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    torch.manual_seed(42)
+    dtype = torch.bfloat16 if (args.dtype == "bf16" and use_cuda) else torch.float32
+
+    model = build_model(args.model, num_classes=1000)
+    if dtype == torch.bfloat16:
+        model.to_compute(device, dtype)
+    else:
+        model.to(device)
+    model.train()
+    hvd.broadcast_parameters(model.state_dict(), root_rank=0)
+
+    lr = 0.001 * world
+    if args.optimizer == "lars":
+        opt = FusedLARS(model.named_parameters(), lr=lr, momentum=0.9, weight_decay=5e-5)
+    else:
+        opt = FusedSGD(model.named_parameters(), lr=lr, momentum=0.9)
+    opt = hvd.DistributedOptimizer(opt, named_parameters=model.named_parameters())
+
+    loader = DeviceSyntheticLoader(args.batch, length=args.batch * world * (args.steps + args.warmup),
+                                   height=args.image, width=args.image, device=device,
+                                   dtype=dtype, rank=rank, world=world)
+
+    def one_step():
+        images, labels = loader.batch()
+        opt.zero_grad()
+        loss = ops.softmax_cross_entropy(model(images), labels)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def sync():
+        hvd.barrier()
+        if use_cuda:
+            torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if use_cuda else "cpu")
+    if world > 1:
+        t = hvd.allreduce(t, op=hvd.Max, name="bench.elapsed")
+    elapsed = float(t.item())
+    final_loss = float(loss.float().item()) if loss is not None else float("nan")
+
+    if rank == 0:
+        global_batch = args.batch * world
+        value = global_batch * args.steps / elapsed
+        base = _read_baseline()
+        # the stock number is a 1-GPU figure; compare per-GPU throughput against it
+        vs = (value / world) / base if base else None
+        print(json.dumps({
+            "metric": "images/sec (whole node) ResNet-50 synthetic 224x224 training",
+            "value": round(value, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None if vs is None else round(vs, 4),
+            "dtype": "bf16" if dtype == torch.bfloat16 else "fp32",
+            "data": "synthetic (on-GPU Philox pool, random-init weights)",
+            "final_loss": round(final_loss, 4),
+            "ops_backend": "hip" if (use_cuda and ops.backend() != "aten") else "aten",
+            "config": {"model": args.model, "global_batch": global_batch,
+                       "per_gpu_batch": args.batch, "image": args.image,
+                       "optimizer": args.optimizer, "parallelism": "dp%d" % world},
+        }))
+    hvd.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,47 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes; all vector accesses are 16 B per lane where alignment allows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DDL_OK 0
+#define DDL_EINVAL (-1)
+#define DDL_EALIGN (-2)
+#define DDL_ELAUNCH (-3)
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // RNE, NaN-preserving
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int ddl_launch_status() {
+    return hipGetLastError() == hipSuccess ? DDL_OK : DDL_ELAUNCH;
+}
+static inline bool ddl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Grid sizing for memory-bound grid-stride kernels: cap at 256 CUs x 8 blocks.
+static inline int ddl_stream_grid(long long work_items, int block) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}

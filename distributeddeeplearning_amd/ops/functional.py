@@ -1,0 +1,126 @@
+"""Functional op surface used by the models.
+
+Each op has two implementations:
+
+* the **HIP path** (``ops/hip_ops.py`` → ``_ddl_kernels.so``): hand-written gfx950 kernels on
+  NHWC bf16 tensors, wrapped in ``torch.autograd.Function``s.  This is the path that runs on
+  MI355X; it fails loudly if the kernel library is missing.
+* the **reference path** (this file, plain PyTorch): used on CPU (tests, the gloo plumbing
+  configuration of BASELINE.json) and as the fp32 numerical oracle for every kernel test.
+  ``DDL_OPS=aten`` forces it on the GPU too, which is how the stock-PyTorch/MIOpen baseline
+  in BASELINE.md is measured.
+
+Semantics follow the reference's model code: conv without bias and explicit padding
+(``HorovodTF/src/resnet_model.py:84-109``), training-mode BatchNorm with momentum 0.1
+(= decay 0.9) and eps 1e-5 (``:10-11,40-49``) followed by ReLU, with the residual form
+``relu(bn(x) + shortcut)`` (``:201-204``), 3×3/2 max-pool (``:264-266``), 7×7 global average
+pool (``:287-289``), dense head (``:293-296``), mean softmax cross-entropy
+(``imagenet_pytorch_horovod.py:340``).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+__all__ = ["use_hip", "conv2d", "batchnorm_act", "maxpool3x3s2", "global_avgpool", "linear",
+           "softmax_cross_entropy", "topk_correct", "set_backend", "backend"]
+
+_FORCED = os.environ.get("DDL_OPS", "auto").lower()  # auto | hip | aten
+
+
+def set_backend(name: str) -> None:
+    global _FORCED
+    if name not in ("auto", "hip", "aten"):
+        raise ValueError(name)
+    _FORCED = name
+
+
+def backend() -> str:
+    return _FORCED
+
+
+def use_hip(t: torch.Tensor) -> bool:
+    """HIP kernels serve CUDA(HIP)-device bf16 tensors unless DDL_OPS=aten."""
+    if _FORCED == "aten" or not t.is_cuda:
+        return False
+    if t.dtype != torch.bfloat16:
+        if _FORCED == "hip":
+            raise RuntimeError("DDL_OPS=hip requires bf16 activations, got %s" % t.dtype)
+        return False
+    from . import kernels
+
+    return kernels.require()
+
+
+# ------------------------------------------------------------------------------------------
+def conv2d(x, weight, stride=1, padding=0):
+    if use_hip(x):
+        from . import hip_ops
+
+        return hip_ops.conv2d(x, weight, stride, padding)
+    return F.conv2d(x, weight.to(x.dtype), None, stride, padding)
+
+
+def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
+                  relu=True, residual=None):
+    """``act(bn(x) [+ residual])`` with act = ReLU or identity; running stats updated in place
+    when training (unbiased variance, like torch)."""
+    if use_hip(x):
+        from . import hip_ops
+
+        return hip_ops.batchnorm_act(x, gamma, beta, running_mean, running_var, training,
+                                     momentum, eps, relu, residual)
+    y = F.batch_norm(x.float() if x.dtype != torch.float32 and not x.is_cuda else x,
+                     running_mean, running_var, gamma, beta, training, momentum, eps)
+    y = y.to(x.dtype)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def maxpool3x3s2(x):
+    if use_hip(x):
+        from . import hip_ops
+
+        return hip_ops.maxpool3x3s2(x)
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
+def global_avgpool(x):
+    """[B,C,H,W] → [B,C]."""
+    if use_hip(x):
+        from . import hip_ops
+
+        return hip_ops.global_avgpool(x)
+    return x.mean(dim=(2, 3))
+
+
+def linear(x, weight, bias=None):
+    if use_hip(x):
+        from . import hip_ops
+
+        return hip_ops.linear(x, weight, bias)
+    return F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
+
+
+def softmax_cross_entropy(logits, target):
+    """Mean softmax cross-entropy, computed in fp32; returns an fp32 scalar."""
+    if logits.is_cuda and _FORCED != "aten":
+        from . import kernels
+
+        if kernels.require():
+            from . import hip_ops
+
+            return hip_ops.softmax_cross_entropy(logits, target)
+    return F.cross_entropy(logits.float(), target)
+
+
+def topk_correct(logits, target, ks=(1, 5)):
+    """Number of samples whose label is within the top-k logits, for each k (eval metric;
+    ``imagenet_keras_horovod.py:307`` accuracy + top_k_categorical_accuracy)."""
+    maxk = max(ks)
+    _, pred = logits.float().topk(maxk, dim=1)
+    hit = pred.eq(target.view(-1, 1))
+    return [int(hit[:, :k].any(dim=1).sum().item()) for k in ks]

@@ -1,0 +1,205 @@
+"""Process-group bootstrap: the ``hvd.init/rank/size/local_rank`` half of the Horovod contract.
+
+Parity target: ``hvd.init()``, ``hvd.rank()``, ``hvd.local_rank()``, ``hvd.size()`` as used at
+``HorovodPytorch/src/imagenet_pytorch_horovod.py:62,196,250,261,272,276,331``.
+
+MI355X design: one process per GPU, rendezvous from the environment (``RANK``/``WORLD_SIZE``/
+``LOCAL_RANK``/``MASTER_ADDR``/``MASTER_PORT`` as exported by ``torch.distributed.run`` or by
+our own launcher; OpenMPI's ``OMPI_COMM_WORLD_*`` names are honoured too so an ``mpirun`` line
+from the reference notebooks still works).  The data plane is RCCL over xGMI
+(``torch.distributed`` backend ``"nccl"`` on ROCm); the CPU/gloo backend serves the GPU-less
+plumbing configuration (BASELINE.json config 1) and the tests.  No MPI anywhere.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+import threading
+
+import torch
+import torch.distributed as dist
+
+from ..utils.config import EngineConfig
+
+__all__ = ["init", "shutdown", "is_initialized", "rank", "size", "local_rank", "local_size",
+           "cross_rank", "cross_size", "backend_name", "device", "group", "barrier",
+           "engine_config", "NotInitializedError", "supports_avg"]
+
+
+class NotInitializedError(ValueError):
+    """Raised by rank()/size() before init(); mirrors Horovod raising ValueError there, which
+    the reference relies on in ``_get_rank`` (:59-66)."""
+
+
+class _State:
+    def __init__(self):
+        self.initialized = False
+        self.rank = 0
+        self.size = 1
+        self.local_rank = 0
+        self.local_size = 1
+        self.backend = "single"
+        self.group = None
+        self.owns_default_group = False
+        self.config = EngineConfig()
+        self.lock = threading.Lock()
+
+
+_S = _State()
+
+
+def _env_first(*names, default=None):
+    for n in names:
+        v = os.environ.get(n)
+        if v not in (None, ""):
+            return v
+    return default
+
+
+def init(backend: str | None = None, timeout_s: float | None = None) -> None:
+    """Idempotent global initialisation.
+
+    With ``WORLD_SIZE`` unset (or 1) this is a single-process job: no process group is created
+    and every collective degenerates to a local no-op, which is the reference's
+    ``DISTRIBUTED=False`` behaviour with the same code path.
+    """
+    with _S.lock:
+        if _S.initialized:
+            return
+        cfg = EngineConfig.from_env()
+        _S.config = cfg
+        world = int(_env_first("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", default="1"))
+        rk = int(_env_first("RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", default="0"))
+        lrk = _env_first("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID")
+        lsz = _env_first("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS")
+        want = (backend or cfg.backend or "auto").lower()
+        n_dev = torch.cuda.device_count()
+        if want in ("auto", ""):
+            want = "rccl" if n_dev > 0 else "gloo"
+        if want in ("nccl", "rccl"):
+            want = "rccl"
+            if n_dev == 0:
+                raise RuntimeError("HVD_BACKEND=rccl requested but no GPU is visible")
+        elif want != "gloo":
+            raise ValueError("unknown backend %r (expected rccl|gloo|auto)" % want)
+
+        if lrk is None:
+            lrk = rk % n_dev if n_dev > 0 else rk
+        _S.local_rank = int(lrk)
+        _S.local_size = int(lsz) if lsz is not None else (min(world, n_dev) if n_dev else world)
+        _S.rank, _S.size = rk, world
+
+        if want == "rccl":
+            # Pin the device before the communicator exists: RCCL binds to the current device.
+            torch.cuda.set_device(_S.local_rank % n_dev)
+
+        if world > 1:
+            if dist.is_initialized():
+                _S.group = dist.group.WORLD
+                _S.owns_default_group = False
+            else:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29500")
+                os.environ["RANK"] = str(rk)
+                os.environ["WORLD_SIZE"] = str(world)
+                tmo = datetime.timedelta(seconds=timeout_s or cfg.collective_timeout_s)
+                kwargs = {}
+                if want == "rccl":
+                    kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
+                dist.init_process_group(backend="nccl" if want == "rccl" else "gloo",
+                                        init_method="env://", rank=rk, world_size=world,
+                                        timeout=tmo, **kwargs)
+                _S.group = dist.group.WORLD
+                _S.owns_default_group = True
+            _S.backend = want
+        else:
+            _S.backend = "single"
+        _S.initialized = True
+
+
+def shutdown() -> None:
+    with _S.lock:
+        if not _S.initialized:
+            return
+        if _S.size > 1 and _S.owns_default_group and dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:  # pragma: no cover - teardown best effort
+                pass
+        _S.__init__()
+
+
+def is_initialized() -> bool:
+    return _S.initialized
+
+
+def _require():
+    if not _S.initialized:
+        raise NotInitializedError("distributed layer has not been initialised; call init() first")
+
+
+def rank() -> int:
+    _require()
+    return _S.rank
+
+
+def size() -> int:
+    _require()
+    return _S.size
+
+
+def local_rank() -> int:
+    _require()
+    return _S.local_rank
+
+
+def local_size() -> int:
+    _require()
+    return _S.local_size
+
+
+def cross_rank() -> int:
+    _require()
+    return _S.rank // max(_S.local_size, 1)
+
+
+def cross_size() -> int:
+    _require()
+    return max(_S.size // max(_S.local_size, 1), 1)
+
+
+def backend_name() -> str:
+    """'rccl', 'gloo' or 'single'."""
+    _require()
+    return _S.backend
+
+
+def supports_avg() -> bool:
+    """RCCL fuses the 1/size scaling into the reduction (ncclAvg); gloo does not."""
+    return _S.backend == "rccl"
+
+
+def device() -> torch.device:
+    """The device collectives of this rank run on."""
+    _require()
+    if _S.backend == "rccl" or (_S.backend == "single" and torch.cuda.is_available()):
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def group():
+    _require()
+    return _S.group
+
+
+def engine_config() -> EngineConfig:
+    return _S.config
+
+
+def barrier() -> None:
+    _require()
+    if _S.size > 1:
+        if _S.backend == "rccl":
+            dist.barrier(group=_S.group, device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier(group=_S.group)

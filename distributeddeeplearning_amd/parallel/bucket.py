@@ -1,0 +1,213 @@
+"""Static gradient-bucket planning and flat gradient arenas.
+
+This replaces Horovod's tensor-fusion buffer and per-cycle negotiation (SURVEY §2.2 N1/N2,
+§2.5 X1/X8).  Horovod 0.13 re-negotiates the set of ready tensors every 5 ms and memcpy's them
+into a 64 MB fusion buffer before each ``ncclAllReduce`` [EXT].  Data-parallel training
+produces the same gradients in the same order every step, so here the plan is computed once:
+
+* parameters are laid out in *reverse registration order* (≈ the order backward produces
+  their gradients: fc first, stem last — SURVEY §2.7 "Gradient bytes by stage");
+* each dtype gets one contiguous **arena**; a bucket is a contiguous slice of the arena, so
+  the all-reduce runs in place on the slice — no pack, no unpack;
+* ``param.grad`` is a *view* into the arena (zero-copy; wgrad kernels write straight into the
+  communication buffer);
+* the first bucket is kept small so communication starts early in backward and the last
+  bucket (the stem, tiny) leaves only a latency-bound tail exposed.
+
+Sizing for MI355X/xGMI: RCCL rings are bound by one ≈153 GB/s link, so a 32 MiB
+bucket costs ≈0.4 ms on 8 GPUs — large enough to amortise launch latency, small enough that
+4–6 buckets pipeline behind the remaining backward.  Segment offsets are aligned to 256 B and
+bucket ends to 8 shards × 256 B so that reduce-scatter style kernels can split a bucket evenly
+across 8 peers with 16-byte vector accesses.
+
+The planner itself is pure Python over ``(name, numel, dtype)`` records and has a native twin
+(``csrc/engine/bucket_plan.cpp``) used when the engine library is built; both are covered by
+the same unit test.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Iterable, Sequence
+
+import torch
+
+__all__ = ["Segment", "Bucket", "ArenaPlan", "plan_arenas", "GradArena", "SEG_ALIGN_BYTES",
+           "BUCKET_ALIGN_BYTES"]
+
+SEG_ALIGN_BYTES = 256
+BUCKET_ALIGN_BYTES = 8 * 256
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Segment:
+    name: str
+    offset: int  # elements from arena start
+    numel: int
+    shape: tuple
+    index: int  # position in the caller's parameter list
+
+
+@dataclass
+class Bucket:
+    index: int
+    start: int  # elements from arena start
+    end: int  # exclusive, padded
+    segments: list = field(default_factory=list)
+
+    @property
+    def numel(self) -> int:
+        return self.end - self.start
+
+
+@dataclass
+class ArenaPlan:
+    dtype: torch.dtype
+    numel: int
+    segments: list
+    buckets: list
+
+
+def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_bytes: int,
+                reverse: bool = True) -> dict:
+    """Plan one arena per dtype.
+
+    ``entries`` is a sequence of ``(name, shape, dtype)`` in registration (forward) order.
+    Returns ``{dtype: ArenaPlan}``.  A tensor is never split across buckets; a tensor larger
+    than the cap gets a bucket of its own.
+    """
+    by_dtype: dict = {}
+    order = list(enumerate(entries))
+    if reverse:
+        order.reverse()
+    for idx, (name, shape, dtype) in order:
+        by_dtype.setdefault(dtype, []).append((idx, name, tuple(shape)))
+    plans = {}
+    for dtype, items in by_dtype.items():
+        esize = torch.empty((), dtype=dtype).element_size()
+        seg_align = max(SEG_ALIGN_BYTES // esize, 1)
+        bkt_align = max(BUCKET_ALIGN_BYTES // esize, 1)
+        segments, buckets = [], []
+        cursor = 0
+        cur = Bucket(0, 0, 0)
+        for idx, name, shape in items:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            cap = first_bucket_bytes if not buckets else bucket_cap_bytes
+            used_bytes = (cursor - cur.start) * esize
+            if cur.segments and used_bytes + n * esize > cap:
+                cursor = _round_up(cursor, bkt_align)
+                cur.end = cursor
+                buckets.append(cur)
+                cur = Bucket(len(buckets), cursor, cursor)
+            seg = Segment(name, cursor, n, shape, idx)
+            segments.append(seg)
+            cur.segments.append(seg)
+            cursor = _round_up(cursor + n, seg_align)
+        if cur.segments:
+            cursor = _round_up(cursor, bkt_align)
+            cur.end = cursor
+            buckets.append(cur)
+        plans[dtype] = ArenaPlan(dtype, cursor, segments, buckets)
+    return plans
+
+
+def _shaped_view(flat: torch.Tensor, seg: Segment, like: torch.Tensor) -> torch.Tensor:
+    """View of ``flat[seg]`` with ``like``'s logical shape and dense stride order (so a
+    channels-last conv weight keeps KRSC storage inside the arena)."""
+    chunk = flat[seg.offset: seg.offset + seg.numel]
+    if like.dim() == 4 and like.is_contiguous(memory_format=torch.channels_last) \
+            and not like.is_contiguous():
+        o, i, r, s = like.shape
+        return chunk.view(o, r, s, i).permute(0, 3, 1, 2)
+    return chunk.view(like.shape)
+
+
+class GradArena:
+    """Flat gradient storage for a list of parameters, with ``param.grad`` views.
+
+    Optionally also relocates the parameters themselves into a flat arena with the same
+    offsets (``flatten_params=True``) so that a fused optimizer can update a whole bucket with
+    one kernel launch over ``params[a:b], grads[a:b], momentum[a:b]``.
+    """
+
+    def __init__(self, named_params: Iterable, first_bucket_bytes: int, bucket_cap_bytes: int,
+                 flatten_params: bool = False, grad_dtype=None):
+        named = [(n, p) for n, p in named_params if p.requires_grad]
+        if not named:
+            raise ValueError("no trainable parameters")
+        names = [n for n, _ in named]
+        if len(set(names)) != len(names):
+            dup = sorted({n for n in names if names.count(n) > 1})
+            raise ValueError("parameter names are not unique: %s" % ", ".join(dup[:5]))
+        devices = {p.device for _, p in named}
+        if len(devices) != 1:
+            raise ValueError("all parameters must live on one device, got %s" % devices)
+        self.device = devices.pop()
+        self.named = named
+        gdt = (lambda p: grad_dtype or p.dtype)
+        self.plans = plan_arenas([(n, p.shape, gdt(p)) for n, p in named],
+                                 first_bucket_bytes, bucket_cap_bytes)
+        self.grads = {dt: torch.zeros(pl.numel, dtype=dt, device=self.device)
+                      for dt, pl in self.plans.items()}
+        self.params = {}
+        self.param_of_segment = {}
+        self.bucket_of_param = {}
+        self.views = {}
+        for dt, plan in self.plans.items():
+            if flatten_params:
+                self.params[dt] = torch.zeros(plan.numel, dtype=dt, device=self.device)
+            for b in plan.buckets:
+                for seg in b.segments:
+                    p = named[seg.index][1]
+                    if flatten_params:
+                        pv = _shaped_view(self.params[dt], seg, p)
+                        with torch.no_grad():
+                            pv.copy_(p)
+                        p.data = pv
+                    gv = _shaped_view(self.grads[dt], seg, p)
+                    p.grad = gv
+                    self.views[id(p)] = gv
+                    self.param_of_segment[(dt, seg.offset)] = p
+                    self.bucket_of_param[id(p)] = (dt, b.index)
+
+    def all_buckets(self):
+        """[(dtype, Bucket)] in planned launch order (largest-dtype arenas interleaved by
+        bucket index so early buckets of every dtype go first)."""
+        out = []
+        for dt, plan in self.plans.items():
+            out.extend((dt, b) for b in plan.buckets)
+        out.sort(key=lambda t: t[1].index)
+        return out
+
+    def bucket_tensor(self, dtype, bucket: Bucket) -> torch.Tensor:
+        return self.grads[dtype][bucket.start: bucket.end]
+
+    def zero_(self):
+        for g in self.grads.values():
+            g.zero_()
+
+    def ensure_view(self, p) -> torch.Tensor:
+        """Re-attach ``p.grad`` to its arena slot if user code replaced or dropped it."""
+        view = self.views[id(p)]
+        if p.grad is None:
+            p.grad = view
+        elif p.grad.data_ptr() != view.data_ptr():
+            with torch.no_grad():
+                view.copy_(p.grad)
+            p.grad = view
+        return view
+
+    def describe(self) -> str:
+        lines = []
+        for dt, plan in self.plans.items():
+            for b in plan.buckets:
+                esz = self.grads[dt].element_size()
+                lines.append("%s bucket %d: %d tensors, %.2f MiB" % (
+                    str(dt).replace("torch.", ""), b.index, len(b.segments),
+                    b.numel * esz / 2 ** 20))
+        return "\n".join(lines)

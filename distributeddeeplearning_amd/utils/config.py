@@ -1,0 +1,182 @@
+"""Typed configuration from the reference's environment-variable contract.
+
+The reference has no argparse and no config files: module-level ``os.getenv`` reads are the
+whole flag system (``imagenet_pytorch_horovod.py:35-53``).  This module keeps the
+same variable names but parses them with types, fixing the reference's quirks instead of
+replicating them: ``EPOCHS`` is an int (#1), booleans accept only real truthy
+spellings rather than "any string containing t" (#2), validation data comes from the TEST
+directory (#3).
+
+Engine tunables use ``HVD_*`` names and also honour Horovod's ``HOROVOD_*`` spellings
+(SURVEY §5.6).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from dataclasses import dataclass, field, fields
+from typing import Optional
+
+__all__ = ["str_to_bool", "env_int", "env_float", "env_bool", "env_str", "TrainConfig",
+           "EngineConfig", "IMAGENET_TRAIN_LEN", "RGB_MEAN", "RGB_SD"]
+
+IMAGENET_TRAIN_LEN = 1281167  # reference default FAKE_DATA_LENGTH (:50-52)
+RGB_MEAN = (0.485, 0.456, 0.406)  # reference :41
+RGB_SD = (0.229, 0.224, 0.225)  # reference :42
+
+_TRUE = {"1", "true", "t", "yes", "y", "on"}
+_FALSE = {"0", "false", "f", "no", "n", "off", ""}
+
+
+def str_to_bool(value) -> bool:
+    """Strict boolean parsing (the reference's ``_str_to_bool`` :28-32 is a substring test)."""
+    if isinstance(value, bool):
+        return value
+    s = str(value).strip().lower()
+    if s in _TRUE:
+        return True
+    if s in _FALSE:
+        return False
+    raise ValueError("cannot interpret %r as a boolean" % (value,))
+
+
+def env_str(name, default=None, *aliases):
+    for key in (name,) + aliases:
+        if key in os.environ:
+            return os.environ[key]
+    return default
+
+
+def env_int(name, default, *aliases) -> int:
+    raw = env_str(name, None, *aliases)
+    return int(default) if raw is None or raw == "" else int(float(raw))
+
+
+def env_float(name, default, *aliases) -> float:
+    raw = env_str(name, None, *aliases)
+    return float(default) if raw is None or raw == "" else float(raw)
+
+
+def env_bool(name, default=False, *aliases) -> bool:
+    raw = env_str(name, None, *aliases)
+    return bool(default) if raw is None else str_to_bool(raw)
+
+
+@dataclass
+class TrainConfig:
+    """Training-script settings; defaults are the reference's constants (:35-53)."""
+
+    width: int = 224
+    height: int = 224
+    channels: int = 3
+    num_classes: int = 1000
+    lr: float = 0.001  # scaled by world size at optimizer construction (:333)
+    momentum: float = 0.9
+    weight_decay: float = 0.0  # reference defines 5e-5 (:47) but never applies it in PyTorch
+    warmup_epochs: int = 0  # reference defines 5 (:46) but only Keras uses it
+    epochs: int = 1
+    batch_size: int = 64  # per GPU (:40)
+    seed: int = 42
+    distributed: bool = False
+    fake: bool = True
+    fake_data_length: int = IMAGENET_TRAIN_LEN
+    validation: bool = False
+    train_dir: Optional[str] = None
+    test_dir: Optional[str] = None
+    output_dir: Optional[str] = None  # rank-0 checkpoint directory
+    temp_dir: Optional[str] = None  # other ranks' scratch directory
+    num_workers: int = 5
+    log_interval: int = 100
+    model: str = "resnet50"
+    dtype: str = "bf16"
+    optimizer: str = "sgd"  # sgd | lars
+    device_data: bool = True  # on-GPU synthetic generator instead of the host FakeData loader
+    resume: bool = True
+    metrics_path: Optional[str] = None
+    max_steps: int = 0  # 0 = whole epoch
+
+    @classmethod
+    def from_env(cls, **overrides) -> "TrainConfig":
+        cfg = cls(
+            epochs=env_int("EPOCHS", 1),
+            batch_size=env_int("BATCHSIZE", 64, "BATCH_SIZE"),
+            lr=env_float("LR", 0.001),
+            momentum=env_float("MOMENTUM", 0.9),
+            weight_decay=env_float("WEIGHT_DECAY", 0.0),
+            warmup_epochs=env_int("WARMUP_EPOCHS", 0),
+            distributed=env_bool("DISTRIBUTED", False),
+            fake=env_bool("FAKE", True),
+            fake_data_length=env_int("FAKE_DATA_LENGTH", IMAGENET_TRAIN_LEN),
+            validation=env_bool("VALIDATION", False),
+            train_dir=env_str("AZ_BATCHAI_INPUT_TRAIN", None, "INPUT_TRAIN_DIR"),
+            test_dir=env_str("AZ_BATCHAI_INPUT_TEST", None, "INPUT_TEST_DIR"),
+            output_dir=env_str("AZ_BATCHAI_OUTPUT_MODEL", None, "OUTPUT_MODEL_DIR"),
+            temp_dir=env_str("AZ_BATCHAI_JOB_TEMP_DIR", None, "JOB_TEMP_DIR"),
+            num_workers=env_int("NUM_WORKERS", 5),
+            model=env_str("MODEL", "resnet50"),
+            dtype=env_str("DTYPE", "bf16"),
+            optimizer=env_str("OPTIMIZER", "sgd"),
+            device_data=env_bool("DEVICE_DATA", True),
+            resume=env_bool("RESUME", True),
+            metrics_path=env_str("METRICS_PATH", None),
+            max_steps=env_int("MAX_STEPS", 0),
+            log_interval=env_int("LOG_INTERVAL", 100),
+        )
+        for k, v in overrides.items():
+            if v is not None:
+                setattr(cfg, k, v)
+        return cfg
+
+    @classmethod
+    def add_arguments(cls, parser: argparse.ArgumentParser) -> argparse.ArgumentParser:
+        """One ``--flag`` per field; unset flags fall back to the environment value."""
+        for f in fields(cls):
+            flag = "--" + f.name.replace("_", "-")
+            if f.type in ("bool", bool):
+                parser.add_argument(flag, type=str_to_bool, default=None, metavar="BOOL")
+            elif f.type in ("int", int):
+                parser.add_argument(flag, type=int, default=None)
+            elif f.type in ("float", float):
+                parser.add_argument(flag, type=float, default=None)
+            else:
+                parser.add_argument(flag, type=str, default=None)
+        return parser
+
+    @classmethod
+    def from_args(cls, argv=None) -> "TrainConfig":
+        parser = cls.add_arguments(argparse.ArgumentParser(description=cls.__doc__))
+        ns = parser.parse_args(argv)
+        return cls.from_env(**vars(ns))
+
+
+@dataclass
+class EngineConfig:
+    """Gradient-exchange engine tunables."""
+
+    fusion_threshold: int = 32 * 1024 * 1024  # bytes per bucket cap
+    first_bucket_bytes: int = 8 * 1024 * 1024  # small first bucket: comm starts early in backward
+    comm_dtype: str = "auto"  # auto = gradient dtype | bf16 | fp32
+    backend: str = "auto"  # auto | rccl | gloo
+    timeline: Optional[str] = None
+    debug: bool = False
+    collective_timeout_s: float = 300.0
+    stall_warning_s: float = 60.0  # Horovod's stall-check default [EXT]
+    fault_inject: Optional[str] = None  # "rank:step"
+    cycle_time_ms: float = 0.0  # accepted for Horovod compat; static buckets need no cycle
+
+    @classmethod
+    def from_env(cls) -> "EngineConfig":
+        return cls(
+            fusion_threshold=env_int("HVD_FUSION_THRESHOLD", 32 * 1024 * 1024,
+                                     "HOROVOD_FUSION_THRESHOLD"),
+            first_bucket_bytes=env_int("HVD_FIRST_BUCKET_BYTES", 8 * 1024 * 1024),
+            comm_dtype=env_str("HVD_COMM_DTYPE", "auto"),
+            backend=env_str("HVD_BACKEND", "auto"),
+            timeline=env_str("HVD_TIMELINE", None, "HOROVOD_TIMELINE"),
+            debug=env_bool("HVD_DEBUG", False),
+            collective_timeout_s=env_float("HVD_COLLECTIVE_TIMEOUT_S", 300.0),
+            stall_warning_s=env_float("HVD_STALL_WARNING_S", 60.0,
+                                      "HOROVOD_STALL_CHECK_TIME_SECONDS"),
+            fault_inject=env_str("HVD_FAULT_INJECT", None),
+            cycle_time_ms=env_float("HVD_CYCLE_TIME", 0.0, "HOROVOD_CYCLE_TIME"),
+        )

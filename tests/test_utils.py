@@ -1,0 +1,173 @@
+"""L0 utilities: Timer, logger, typed config, dotenv helpers (SURVEY §4 unit list)."""
+import io
+import logging
+import os
+
+import pytest
+
+from distributeddeeplearning_amd.utils import env as envmod
+from distributeddeeplearning_amd.utils.config import (EngineConfig, TrainConfig, env_int,
+                                                      str_to_bool)
+from distributeddeeplearning_amd.utils.logging import LOG_FORMAT, MetricsWriter, RankAdapter
+from distributeddeeplearning_amd.utils.timer import Timer, timer
+
+
+class FakeClock:
+    def __init__(self):
+        self.t = 0.0
+
+    def __call__(self):
+        return self.t
+
+
+def test_timer_live_then_frozen():
+    clk = FakeClock()
+    t = Timer(timer=clk)
+    t.start()
+    clk.t = 2.0
+    assert t.elapsed == 2.0
+    clk.t = 3.5
+    t.stop()
+    clk.t = 10.0
+    assert t.elapsed == 3.5
+    assert str(t) == "3.500"
+
+
+def test_timer_factor_and_context_output():
+    clk = FakeClock()
+    out = []
+    with Timer(timer=clk, factor=1000, output=out.append, prefix="Training",
+               fmt="took {:.1f} ms") as t:
+        clk.t = 0.25
+        assert t.elapsed == 250.0
+    assert out == ["Training took 250.0 ms"]
+
+
+def test_timer_prefix_implies_print(capsys):
+    with Timer(timer=FakeClock(), prefix="X"):
+        pass
+    assert capsys.readouterr().out.strip() == "X took 0.000 seconds"
+
+
+def test_timer_silent_without_output(capsys):
+    with Timer(timer=FakeClock()):
+        pass
+    assert capsys.readouterr().out == ""
+
+
+def test_timer_restart_resets_end():
+    clk = FakeClock()
+    t = Timer(timer=clk)
+    t.start(); clk.t = 1.0; t.stop()
+    t.start(); clk.t = 1.5
+    assert t.elapsed == 0.5
+
+
+def test_timer_decorator_bare_and_with_logger(capsys):
+    @timer
+    def f(x):
+        return x + 1
+
+    assert f(1) == 2
+    assert "function f execution time" in capsys.readouterr().out
+    records = []
+
+    class H(logging.Handler):
+        def emit(self, r):
+            records.append(r)
+
+    lg = logging.getLogger("timer-test")
+    lg.setLevel(logging.DEBUG)
+    lg.addHandler(H())
+
+    @timer(logger=lg, level=logging.DEBUG)
+    def g():
+        return 7
+
+    assert g() == 7
+    assert records and records[0].function_name == "g" and records[0].execution_time >= 0
+
+
+def test_logger_format_matches_reference():
+    stream = io.StringIO()
+    base = logging.getLogger("fmt-test")
+    base.setLevel(logging.INFO)
+    h = logging.StreamHandler(stream)
+    h.setFormatter(logging.Formatter(LOG_FORMAT))
+    base.addHandler(h)
+    base.propagate = False
+    lg = RankAdapter(base)
+    lg.info("hello")
+    lg.set_epoch(3)
+    lg.info("again")
+    lines = stream.getvalue().splitlines()
+    assert lines[0] == "INFO:fmt-test:0:  hello"
+    assert lines[1] == "INFO:fmt-test:0: [Epoch 3] again"
+
+
+def test_str_to_bool_is_strict():
+    assert str_to_bool("True") and str_to_bool("1") and str_to_bool("yes")
+    assert not str_to_bool("False") and not str_to_bool("0") and not str_to_bool("")
+    # the reference's substring test calls these True
+    for bad in ("not", "testing"):
+        with pytest.raises(ValueError):
+            str_to_bool(bad)
+
+
+def test_config_from_env_types(monkeypatch):
+    monkeypatch.setenv("EPOCHS", "3")
+    monkeypatch.setenv("DISTRIBUTED", "True")
+    monkeypatch.setenv("FAKE", "False")
+    monkeypatch.setenv("FAKE_DATA_LENGTH", "1000")
+    monkeypatch.setenv("AZ_BATCHAI_OUTPUT_MODEL", "/tmp/out")
+    cfg = TrainConfig.from_env()
+    assert cfg.epochs == 3 and isinstance(cfg.epochs, int)
+    assert cfg.distributed is True and cfg.fake is False
+    assert cfg.fake_data_length == 1000 and cfg.output_dir == "/tmp/out"
+    assert list(range(cfg.epochs)) == [0, 1, 2]  # reference raises here (§2.11 #1)
+    assert cfg.batch_size == 64 and cfg.lr == 0.001 and cfg.momentum == 0.9
+
+
+def test_config_args_override_env(monkeypatch):
+    monkeypatch.setenv("EPOCHS", "3")
+    cfg = TrainConfig.from_args(["--epochs", "5", "--fake", "true", "--model", "resnet18"])
+    assert cfg.epochs == 5 and cfg.fake is True and cfg.model == "resnet18"
+
+
+def test_engine_config_honours_horovod_names(monkeypatch):
+    monkeypatch.setenv("HOROVOD_FUSION_THRESHOLD", str(16 << 20))
+    monkeypatch.setenv("HOROVOD_TIMELINE", "/tmp/tl.json")
+    cfg = EngineConfig.from_env()
+    assert cfg.fusion_threshold == 16 << 20 and cfg.timeline == "/tmp/tl.json"
+    monkeypatch.setenv("HVD_FUSION_THRESHOLD", str(4 << 20))
+    assert EngineConfig.from_env().fusion_threshold == 4 << 20
+    assert env_int("NOPE_NOT_SET", 7) == 7
+
+
+def test_dotenv_roundtrip(tmp_path):
+    path = envmod.dotenv_for(str(tmp_path))
+    assert os.path.isfile(path)
+    envmod.set_key(path, "GROUP_NAME", "rg1")
+    envmod.set_key(path, "NUM_NODES", 2)
+    assert envmod.get_key(path, "GROUP_NAME") == "rg1"
+    assert envmod.get_key(path, "NUM_NODES") == "2"
+    sub = tmp_path / "a" / "b"
+    sub.mkdir(parents=True)
+    assert envmod.dotenv_for(str(sub)) == path  # found by walking up
+    envmod.set_key(path, "PASSWORD", "s3cret")
+    assert envmod.get_password(path) == "s3cret"
+    envmod.write_json_to_file({"a": 1}, str(tmp_path / "job.json"))
+    assert (tmp_path / "job.json").read_text().strip().startswith("{")
+
+
+def test_metrics_writer(tmp_path):
+    import json
+
+    p = tmp_path / "m" / "metrics.jsonl"
+    with MetricsWriter(str(p), rank=0) as w:
+        w.write(step=1, loss=2.5)
+    rec = json.loads(p.read_text().splitlines()[0])
+    assert rec["step"] == 1 and rec["loss"] == 2.5 and rec["rank"] == 0
+    w2 = MetricsWriter(str(tmp_path / "n.jsonl"), rank=1)
+    w2.write(step=1)
+    assert not (tmp_path / "n.jsonl").exists()
