@@ -54,7 +54,7 @@ def build_kernels(force=False, jobs=8, verbose=True):
         return None
     os.makedirs(os.path.join(BUILD, "kernels"), exist_ok=True)
     hipcc = _hipcc()
-    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffast-math",
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-math-errno", "-ffp-contract=fast",
              "-fno-gpu-sanitize", "-Wno-unused-result", "-I", os.path.join(ROOT, "csrc", "kernels")]
     todo, objs = [], []
     for s in srcs:

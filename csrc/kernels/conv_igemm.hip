@@ -1,0 +1,292 @@
+// K1/K2/K3/K5: implicit-GEMM convolution forward and backward-data on bf16 MFMA (gfx950).
+//
+//   y[m][n] = sum_{r,s,c} x[b, ho*ostride - pad + r, wo*ostride - pad + s, c] * w[n][r][s][c]
+//
+// with m = (b, ho, wo) linearised, x NHWC bf16, w "KRSC" bf16 (n-major, k contiguous), y NHWC
+// bf16, fp32 accumulation.  The same kernel serves
+//   * forward conv (any RxS, stride, pad; Cin % 32 == 0),
+//   * 1x1 convs and the dense head (R = S = H = W = 1)  -> plain GEMM,
+//   * the stem 7x7/2 conv through the "row-of-taps" view (R = 7, S = 1, C = 32 over a W-padded
+//     NHWC4 image: one tap row = 8 taps x 4 channels = 64 contiguous bytes),
+//   * backward-data: dx = conv(dy dilated by the forward stride, flipped/transposed weights
+//     "CRSK") with ostride = 1 and input dilation idil = forward stride.
+//
+// Structure (CDNA4): 256 threads = 4 waves (2 x 2), block tile BM x BN x BK, wave tile
+// BM/2 x BN/2 of v_mfma_f32_16x16x32_bf16 fragments.  Operand tiles are staged
+// global -> registers (buffer_load_dwordx4: out-of-image taps and M/N edges read as zero through
+// the buffer range check, no branches) -> LDS (XOR-swizzled 16-byte chunks, conflict-free
+// ds_read_b128 fragment reads), double-buffered, one barrier per K tile.  The product is
+// computed swapped (D rows = output channels, D cols = pixels) so each lane owns 4 consecutive
+// channels; the epilogue stages the bf16 tile through LDS and stores whole rows with 16-byte
+// lanes, optionally adding a residual tensor (backward shortcut fusion) and emitting per-tile
+// per-channel sum / sum-of-squares partials for BatchNorm (K6 fused: saves one full read of y).
+#include "common.h"
+
+namespace {
+
+struct IGemmParams {
+    const bf16_t* x;
+    const bf16_t* w;
+    bf16_t* y;
+    const bf16_t* addend;  // optional [M][N], added in the epilogue
+    float* stats;          // optional [tilesM][2][N] partial sums of y and y^2 (bf16-rounded y)
+    unsigned x_bytes, w_bytes;
+    int Hin, Win, C;       // input image (logical, before dilation) and reduction channels
+    long long xs_b, xs_h, xs_w;  // element strides of the input
+    int Hout, Wout, N, M;
+    int R, S, ostride, pad, pad_w, idil_log2;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+}
+
+// byte offset of 16-byte chunk `ch` of row `row` in a [rows][BK] bf16 LDS tile (swizzled)
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int ch) {
+    if (BK == 64) return row * 128 + ((ch ^ (row & 7)) << 4);
+    return row * 64 + ((ch ^ ((0 - (row >> 2)) & 3)) << 4);
+}
+
+template <int BM, int BN, int BK, bool STATS, bool ADDEND>
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p) {
+    constexpr int CPR = BK / 8;            // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPR;         // rows covered per pass of the 256 threads
+    constexpr int A_LOADS = BM / RPP, B_LOADS = BN / RPP;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int OSTR = BN * 2 + 16;        // padded out-tile row stride (bytes)
+    constexpr int EPI_BYTES = BM * OSTR + 8 * BN * 4;  // out tile + [4 waves][2][BN] fp32 stats scratch
+    constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
+    // contiguous run of logical tiles, n fastest, so the A panel of an M tile is reused in L2.
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+    const int ch = tid % CPR, row0 = tid / CPR;
+    const int Kdim = p.R * p.S * p.C;
+    // per-row A state
+    long long a_base[A_LOADS];
+    int a_h0[A_LOADS], a_w0[A_LOADS];
+    const int hw = p.Hout * p.Wout;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        int m = m0 + row0 + i * RPP;
+        if (m < p.M) {
+            int b = m / hw, rem = m - b * hw;
+            int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+            a_h0[i] = ho * p.ostride - p.pad;
+            a_w0[i] = wo * p.ostride - p.pad_w;
+            a_base[i] = (long long)b * p.xs_b + ch * 8;
+        } else {
+            a_h0[i] = -(1 << 28); a_w0[i] = 0; a_base[i] = 0;  // never valid
+        }
+    }
+    unsigned b_off[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        int n = n0 + row0 + i * RPP;
+        long long o = ((long long)n * Kdim + ch * 8) * 2;
+        b_off[i] = (n < p.N && o < 0x7fffffffLL) ? (unsigned)o : 0x80000000u;
+    }
+
+    const int idil_mask = (1 << p.idil_log2) - 1;
+    const int cpt = p.C / BK;          // K tiles per filter tap
+    const int KT = p.R * p.S * cpt;
+    int kr = 0, ks = 0, kc = 0;        // tap / channel-block counters of the tile being fetched
+
+    u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int th = a_h0[i] + kr, tw = a_w0[i] + ks;
+            bool ok = (th >= 0) & (tw >= 0) & (((th | tw) & idil_mask) == 0);
+            int hi = th >> p.idil_log2, wi = tw >> p.idil_log2;
+            ok = ok & (hi < p.Hin) & (wi < p.Win);
+            long long e = a_base[i] + (long long)hi * p.xs_h + (long long)wi * p.xs_w + kc * BK;
+            a_reg[i] = buf_load16(xr, ok ? (unsigned)(e * 2) : 0x80000000u);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            b_reg[i] = buf_load16(wr, b_off[i] == 0x80000000u ? b_off[i] : b_off[i] + (unsigned)kt * (BK * 2));
+        if (++kc == cpt) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+    };
+    auto stash = [&](int stage) {
+        unsigned char* As = smem + stage * STAGE;
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            *reinterpret_cast<u32x4*>(As + lds_off<BK>(row0 + i * RPP, ch)) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            *reinterpret_cast<u32x4*>(Bs + lds_off<BK>(row0 + i * RPP, ch)) = b_reg[i];
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) fetch(kt + 1);
+        const unsigned char* As = smem + cur * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 xa[FM], wb[FN];
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+                xa[j] = *reinterpret_cast<const bf16x8*>(As + lds_off<BK>(wm * WM + j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                wb[i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * WN + i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], xa[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc -> bf16 tile in LDS ([BM][BN], row stride OSTR) -> coalesced stores ----
+    unsigned char* Os = smem;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = f2bf(acc[i][j][e]);
+            int m = wm * WM + j * 16 + fr, n = wn * WN + i * 16 + fq * 4;
+            *reinterpret_cast<bf16x4*>(Os + m * OSTR + n * 2) = v;
+        }
+    __syncthreads();
+    constexpr int OCPR = BN / 8, ORPP = 256 / OCPR, OITER = BM / ORPP;
+    const int oc = tid % OCPR, orow0 = tid / OCPR;
+    const int n = n0 + oc * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < OITER; ++it) {
+        int row = orow0 + it * ORPP, m = m0 + row;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OSTR + oc * 16);
+        if (m < p.M && n < p.N) {
+            long long o = (long long)m * p.N + n;
+            if (ADDEND) {
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(p.addend + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(a[e]));
+            }
+            *reinterpret_cast<bf16x8*>(p.y + o) = v;
+            if (STATS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float f = bf2f(v[e]); s1[e] += f; s2[e] += f * f; }
+            }
+        }
+    }
+    if (STATS) {
+        // lanes with equal (tid % OCPR) hold the same channels: fold the wave, then the 4 waves
+        float* red = reinterpret_cast<float*>(smem + BM * OSTR);  // [4 waves][2][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = OCPR; o < 64; o <<= 1) {
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+        }
+        float* r1 = red + wid * 2 * BN;
+        if (lane < OCPR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { r1[lane * 8 + e] = s1[e]; r1[BN + lane * 8 + e] = s2[e]; }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            float t = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
+            int which = tid / BN, c = tid - which * BN;
+            if (n0 + c < p.N) p.stats[((long long)tile_m * 2 + which) * p.N + n0 + c] = t;
+        }
+    }
+}
+
+template <int BM, int BN, int BK>
+int launch_cfg(const IGemmParams& p, hipStream_t stream) {
+    dim3 grid(p.tiles_m * p.tiles_n), block(256);
+    if (p.stats && p.addend) return DDL_EINVAL;
+    if (p.stats) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, true, false>), grid, block, 0, stream, p);
+    else if (p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, false, false>), grid, block, 0, stream, p);
+    return ddl_launch_status();
+}
+
+}  // namespace
+
+// Number of M tiles the forward kernel uses for a problem (so callers can size `stats`).
+extern "C" int ddl_conv_igemm_tiles_m(long long M) { return (int)((M + 127) / 128); }
+
+extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void* addend, void* stats,
+                              long long x_numel, long long w_numel,
+                              int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                              int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
+                              hipStream_t stream) {
+    if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || N <= 0 || R <= 0 || S <= 0) return DDL_EINVAL;
+    if (C % 32 != 0 || N % 8 != 0) return DDL_EINVAL;
+    if (idil != 1 && idil != 2 && idil != 4) return DDL_EINVAL;
+    if (ostride <= 0 || pad < 0 || pad_w < 0 || Hout <= 0 || Wout <= 0) return DDL_EINVAL;
+    if (x_numel * 2 >= 0x7fffffffLL || w_numel * 2 >= 0x7fffffffLL) return DDL_EINVAL;
+    if (w_numel < (long long)N * R * S * C) return DDL_EINVAL;
+    if (!ddl_aligned16(x) || !ddl_aligned16(w) || !ddl_aligned16(y) || (addend && !ddl_aligned16(addend))) return DDL_EALIGN;
+    if ((xs_b % 8) || (xs_h % 8)) return DDL_EALIGN;
+    // every tap address must be 16-byte aligned: either pixels are >= 8 elements apart, or (S == 1,
+    // undilated) only multiples of ostride are visited and those are
+    if (xs_w % 8) {
+        if (S != 1 || idil != 1 || ((long long)ostride * xs_w) % 8 || ((long long)pad_w * xs_w) % 8) return DDL_EALIGN;
+    }
+    long long M = (long long)B * Hout * Wout;
+    if (M >= (1LL << 31)) return DDL_EINVAL;
+    // the farthest element any valid tap can touch must lie inside the buffer
+    long long last = (long long)(B - 1) * xs_b + (long long)(Hin - 1) * xs_h + (long long)(Win - 1) * xs_w + C;
+    if (last > x_numel) return DDL_EINVAL;
+    IGemmParams p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
+    p.addend = (const bf16_t*)addend; p.stats = (float*)stats;
+    p.x_bytes = (unsigned)(x_numel * 2); p.w_bytes = (unsigned)(w_numel * 2);
+    p.Hin = Hin; p.Win = Win; p.C = C; p.xs_b = xs_b; p.xs_h = xs_h; p.xs_w = xs_w;
+    p.Hout = Hout; p.Wout = Wout; p.N = N; p.M = (int)M;
+    p.R = R; p.S = S; p.ostride = ostride; p.pad = pad; p.pad_w = pad_w;
+    p.idil_log2 = idil == 1 ? 0 : (idil == 2 ? 1 : 2);
+    p.tiles_m = (int)((M + 127) / 128);
+    const bool bk64 = (C % 64 == 0);
+    if (N <= 64) {
+        p.tiles_n = (N + 63) / 64;
+        return bk64 ? launch_cfg<128, 64, 64>(p, stream) : launch_cfg<128, 64, 32>(p, stream);
+    }
+    p.tiles_n = (N + 127) / 128;
+    return bk64 ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
+}

@@ -1,0 +1,298 @@
+// K4: convolution backward-weights as a split-K implicit GEMM on bf16 MFMA (gfx950).
+//
+//   dw[n][r][s][c] = sum_m dy[m][n] * x[b, ho*stride - pad + r, wo*stride - pad + s, c]
+//
+// GEMM view: rows = output channels n, cols = (r, s, c), reduction = m = (b, ho, wo) — the
+// *slow* axis of both operands.  Tiles of dy [32 m][BMw n] and x [32 m][BNw c] are staged
+// row-major (coalesced 16-byte buffer loads, out-of-image taps read as zero) into padded LDS
+// rows, and the MFMA fragments — which need 8 consecutive reduction elements per lane — are read
+// with the gfx950 transposing LDS load ds_read_b64_tr_b16 (no register shuffles, no transposed
+// copy of the activations in memory).  The reduction index inside one 32-deep MFMA step is
+// permuted identically for both operands (lane group g takes rows 4g..4g+3 and 16+4g..16+4g+3)
+// so that the 8 rows one half-wave touches land in 8 distinct 32-byte bank windows.
+//
+// The reduction (up to B*Ho*Wo = 3.2 M for the stem) is split over workgroups; each writes an
+// fp32 partial slab and `ddl_splitk_reduce` sums the slabs in a fixed order (deterministic,
+// no float atomics) into the gradient arena in bf16 or fp32.
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+    const bf16_t* dy;
+    const bf16_t* x;
+    float* partial;  // [splits][K][RSC]
+    unsigned dy_bytes, x_bytes;
+    int Hin, Win, C;
+    long long xs_b, xs_h, xs_w;
+    int Hout, Wout, K, M;
+    int R, S, stride, pad, pad_w;
+    int tiles_k, tiles_c, splits, m_per_split;
+    int simple;  // x row of pixel m is x + m*xs_w (1x1, stride 1, no padding)
+    float inv_hw, inv_w;
+};
+
+__device__ __forceinline__ u32x4 wg_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
+}
+
+// q = m / d, r = m % d for 0 <= m < 2^24 through an fp32 reciprocal and a one-step fix-up
+__device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r) {
+    q = (int)((float)m * inv);
+    r = m - q * d;
+    if (r >= d) { ++q; r -= d; }
+    if (r < 0) { --q; r += d; }
+}
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+template <int BMw, int BNw>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
+    constexpr int BK = 32;                          // reduction rows per tile
+    constexpr int A_STR = BMw * 2 + 32, B_STR = BNw * 2 + 32;  // padded row strides (bytes)
+    constexpr int A_BYTES = BK * A_STR, B_BYTES = BK * B_STR;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int A_CPR = BMw / 8, B_CPR = BNw / 8;
+    constexpr int A_LOADS = (BK * A_CPR + 255) / 256, B_LOADS = (BK * B_CPR + 255) / 256;
+    constexpr int WM = BMw / 2, WN = BNw / 2;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    const int ntile = p.tiles_k * p.R * p.S * p.tiles_c;
+    const int nwg = ntile * p.splits;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int split = bid / ntile;
+    int t = bid - split * ntile;
+    const int tile_k = t % p.tiles_k; t /= p.tiles_k;
+    const int tile_c = t % p.tiles_c; t /= p.tiles_c;
+    const int fs = t % p.S, frr = t / p.S;
+    const int n0 = tile_k * BMw, c0 = tile_c * BNw;
+
+    const int m_begin = split * p.m_per_split;
+    int m_end = m_begin + p.m_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int KT = (m_end - m_begin + BK - 1) / BK;
+
+    const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+
+    const int hw = p.Hout * p.Wout;
+    u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    auto fetch = [&](int kt) {
+        const int mb = m_begin + kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int idx = tid + i * 256;
+            int row = idx / A_CPR, ch = idx - row * A_CPR;
+            int m = mb + row, n = n0 + ch * 8;
+            bool ok = (row < BK) & (m < m_end) & (n < p.K);
+            long long e = (long long)m * p.K + n;
+            a_reg[i] = wg_load16(dyr, ok ? (unsigned)(e * 2) : 0x80000000u);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int idx = tid + i * 256;
+            int row = idx / B_CPR, ch = idx - row * B_CPR;
+            int m = mb + row, c = c0 + ch * 8;
+            bool ok = (row < BK) & (m < m_end) & (c < p.C);
+            long long e;
+            if (p.simple) {
+                e = (long long)m * p.xs_w + c;
+            } else {
+                int b, rem, ho, wo;
+                fdivmod(m, hw, p.inv_hw, b, rem);
+                fdivmod(rem, p.Wout, p.inv_w, ho, wo);
+                int hi = ho * p.stride - p.pad + frr, wi = wo * p.stride - p.pad_w + fs;
+                ok = ok & (hi >= 0) & (hi < p.Hin) & (wi >= 0) & (wi < p.Win);
+                e = (long long)b * p.xs_b + (long long)hi * p.xs_h + (long long)wi * p.xs_w + c;
+            }
+            b_reg[i] = wg_load16(xr, ok ? (unsigned)(e * 2) : 0x80000000u);
+        }
+    };
+    auto stash = [&](int stage) {
+        unsigned char* As = smem + stage * STAGE;
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int idx = tid + i * 256;
+            int row = idx / A_CPR, ch = idx - row * A_CPR;
+            if (row < BK) *reinterpret_cast<u32x4*>(As + row * A_STR + ch * 16) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int idx = tid + i * 256;
+            int row = idx / B_CPR, ch = idx - row * B_CPR;
+            if (row < BK) *reinterpret_cast<u32x4*>(Bs + row * B_STR + ch * 16) = b_reg[i];
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposing-read addressing: lane 16g + 4q + pq supplies row (4g + q [+16]), cols 4pq..4pq+3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int tr_row = 4 * g + q;
+
+    if (KT > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) fetch(kt + 1);
+        unsigned char* As = smem + cur * STAGE;
+        unsigned char* Bs = As + A_BYTES;
+        bf16x8 af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            unsigned char* a0 = As + tr_row * A_STR + (wm * WM + i * 16 + 4 * pq) * 2;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 16 * A_STR));
+            af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            unsigned char* b0 = Bs + tr_row * B_STR + (wn * WN + j * 16 + 4 * pq) * 2;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(b0));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(b0 + 16 * B_STR));
+            bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (kt + 1 < KT) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // D rows = n (4 per lane), cols = c (lane & 15)
+    const int RSC = p.R * p.S * p.C;
+    float* out = p.partial + (long long)split * p.K * RSC;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            int c = c0 + wn * WN + j * 16 + fr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int n = n0 + wm * WM + i * 16 + fq * 4 + e;
+                if (n < p.K && c < p.C)
+                    out[(long long)n * RSC + (frr * p.S + fs) * p.C + c] = acc[i][j][e];
+            }
+        }
+}
+
+// out[i] = scale * sum_s partial[s][i]  (fixed order), bf16 or fp32 output, optional accumulate
+template <typename OutT, bool ACCUM>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, OutT* __restrict__ out,
+                                                           long long n, int splits, long long slab) {
+    long long n4 = n >> 2;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(partial + (i << 2));
+        for (int k = 1; k < splits; ++k) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long long)k * slab + (i << 2));
+            s += v;
+        }
+        if constexpr (sizeof(OutT) == 4) {
+            f32x4* o = reinterpret_cast<f32x4*>(out + (i << 2));
+            if (ACCUM) s += *o;
+            *o = s;
+        } else {
+            bf16x4* o = reinterpret_cast<bf16x4*>(out + (i << 2));
+            if (ACCUM) { bf16x4 old = *o; for (int e = 0; e < 4; ++e) s[e] += bf2f(old[e]); }
+            bf16x4 v;
+            for (int e = 0; e < 4; ++e) v[e] = f2bf(s[e]);
+            *o = v;
+        }
+    }
+}
+
+template <int BMw, int BNw>
+int launch_wgrad(WgradParams& p, hipStream_t stream) {
+    p.tiles_k = (p.K + BMw - 1) / BMw;
+    p.tiles_c = (p.C + BNw - 1) / BNw;
+    dim3 grid(p.tiles_k * p.tiles_c * p.R * p.S * p.splits), block(256);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw>), grid, block, 0, stream, p);
+    return ddl_launch_status();
+}
+
+}  // namespace
+
+// Split planning shared with the host wrapper: returns the number of reduction splits for a
+// problem so the caller can size the partial workspace (splits * K * R*S*C floats).
+extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S) {
+    int bm = K <= 64 ? 64 : 128, bn = C <= 32 ? 32 : (C <= 64 ? 64 : 128);
+    long long tiles = (long long)((K + bm - 1) / bm) * ((C + bn - 1) / bn) * R * S;
+    long long want = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
+    long long max_by_m = (M + 255) / 256;                  // at least 256 reduction rows per split
+    if (want > max_by_m) want = max_by_m;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    return (int)want;
+}
+
+extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
+                              int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                              int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
+                              hipStream_t stream) {
+    if (!dy || !x || !partial || B <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || splits <= 0) return DDL_EINVAL;
+    if (C % 8 != 0 || K % 8 != 0) return DDL_EINVAL;
+    if (dy_numel * 2 >= 0x7fffffffLL || x_numel * 2 >= 0x7fffffffLL) return DDL_EINVAL;
+    if (!ddl_aligned16(dy) || !ddl_aligned16(x) || !ddl_aligned16(partial)) return DDL_EALIGN;
+    if ((xs_b % 8) || (xs_h % 8)) return DDL_EALIGN;
+    if (xs_w % 8) {
+        if (S != 1 || ((long long)stride * xs_w) % 8 || ((long long)pad_w * xs_w) % 8) return DDL_EALIGN;
+    }
+    long long M = (long long)B * Hout * Wout;
+    if (M >= (1LL << 24) || dy_numel < M * K) return DDL_EINVAL;
+    long long last = (long long)(B - 1) * xs_b + (long long)(Hin - 1) * xs_h + (long long)(Win - 1) * xs_w + C;
+    if (last > x_numel) return DDL_EINVAL;
+    WgradParams p;
+    p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.partial = (float*)partial;
+    p.dy_bytes = (unsigned)(dy_numel * 2); p.x_bytes = (unsigned)(x_numel * 2);
+    p.Hin = Hin; p.Win = Win; p.C = C; p.xs_b = xs_b; p.xs_h = xs_h; p.xs_w = xs_w;
+    p.Hout = Hout; p.Wout = Wout; p.K = K; p.M = (int)M;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.pad_w = pad_w;
+    p.splits = splits;
+    long long mps = (M + splits - 1) / splits;
+    mps = (mps + 31) / 32 * 32;
+    p.m_per_split = (int)mps;
+    p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0 && pad_w == 0 && Hin == Hout && Win == Wout &&
+                xs_h == (long long)Win * xs_w && xs_b == (long long)Hin * xs_h) ? 1 : 0;
+    p.inv_hw = 1.0f / (float)(Hout * Wout);
+    p.inv_w = 1.0f / (float)Wout;
+    if (K <= 64) {
+        if (C <= 32) return launch_wgrad<64, 32>(p, stream);
+        if (C <= 64) return launch_wgrad<64, 64>(p, stream);
+        return launch_wgrad<64, 128>(p, stream);
+    }
+    if (C <= 64) return launch_wgrad<128, 64>(p, stream);
+    return launch_wgrad<128, 128>(p, stream);
+}
+
+extern "C" int ddl_splitk_reduce(const void* partial, void* out, long long n, int splits, long long slab,
+                                 int out_is_bf16, int accumulate, hipStream_t stream) {
+    if (!partial || !out || n <= 0 || splits <= 0 || (n & 3) || slab < n || (slab & 3)) return DDL_EINVAL;
+    if (!ddl_aligned16(partial) || (reinterpret_cast<uintptr_t>(out) & 7)) return DDL_EALIGN;
+    if (!out_is_bf16 && !ddl_aligned16(out)) return DDL_EALIGN;
+    dim3 grid(ddl_stream_grid(n / 4, 256)), block(256);
+#define RL(T, A) hipLaunchKernelGGL((splitk_reduce_kernel<T, A>), grid, block, 0, stream, (const float*)partial, (T*)out, n, splits, slab)
+    if (out_is_bf16) { if (accumulate) RL(bf16_t, true); else RL(bf16_t, false); }
+    else { if (accumulate) RL(float, true); else RL(float, false); }
+#undef RL
+    return ddl_launch_status();
+}

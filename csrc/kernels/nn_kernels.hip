@@ -1,0 +1,655 @@
+// Memory-bound network kernels on NHWC bf16 activations:
+//   K6  bn_stats_partial / bn_fwd_finalize   per-channel batch statistics (fp32, Chan-combined)
+//   K7  bn_apply_fwd                         z = relu(y*scale + shift [+ residual])
+//   K8  bn_bwd_reduce / _finalize / _apply   dgamma, dbeta, dy (+ masked grad for the shortcut)
+//   K10 maxpool3x3s2 fwd/bwd (argmax byte kept), K11 global average pool fwd/bwd
+//   K13 softmax cross-entropy fwd+bwd in one pass, bias add, K3 helper: weight flip-transpose
+// All: wave64, 256-thread blocks unless noted, 16-byte (8 x bf16) lanes, fp32 math.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void load8f(const float* p, float* v) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6a: standalone statistics partials [T][2][C] over tiles of `rows_per_tile` rows (used when the
+// producer is not our conv kernel).  256 threads = (C/8 chunk columns) x row lanes.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_stats_partial_kernel(const bf16_t* __restrict__ y, float* __restrict__ partial,
+                                                              long long M, int C, int rows_per_tile) {
+    __shared__ float red[2][256 * 8 / 1];  // [2][rowlane*C8*8] folded below (max 2048 floats each)
+    const int cchunks = C >> 3, rlanes = 256 / cchunks;
+    const int cc = threadIdx.x % cchunks, rl = threadIdx.x / cchunks;
+    const long long r0 = (long long)blockIdx.x * rows_per_tile;
+    long long r1 = r0 + rows_per_tile;
+    if (r1 > M) r1 = M;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (long long r = r0 + rl; r < r1; r += rlanes) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(y + r * C + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float f = bf2f(v[e]); s1[e] += f; s2[e] += f * f; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x * 8 + e] = s1[e]; red[1][threadIdx.x * 8 + e] = s2[e]; }
+    __syncthreads();
+    // thread t < 2*C sums the row lanes of channel (t % C)
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        int which = t / C, c = t - which * C;
+        float acc = 0.f;
+        for (int l = 0; l < rlanes; ++l) acc += red[which][(l * cchunks + (c >> 3)) * 8 + (c & 7)];
+        partial[((long long)blockIdx.x * 2 + which) * C + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6b: combine tile partials (sum, sum of squares over rows_per_tile rows each) into mean / invstd
+// with Chan's parallel-variance update (cancellation stays inside a tile), update the running
+// statistics (unbiased variance, like torch) and emit the fused scale/shift of K7.
+// Block = 64 channels x 16 tile lanes.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) bn_fwd_finalize_kernel(const float* __restrict__ partial, int T, int C, long long M,
+                                                              int rows_per_tile, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ rmean,
+                                                              float* __restrict__ rvar, float momentum, float eps,
+                                                              float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                              float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float sn[16][64], sm[16][64], sq[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C) {
+        for (int t = ty; t < T; t += 16) {
+            long long rows = M - (long long)t * rows_per_tile;
+            if (rows > rows_per_tile) rows = rows_per_tile;
+            float nt = (float)rows;
+            float a = partial[((long long)t * 2) * C + c], b = partial[((long long)t * 2 + 1) * C + c];
+            float mt = a / nt, m2t = fmaxf(b - a * mt, 0.f);
+            float tot = n + nt, d = mt - mean;
+            mean += d * (nt / tot);
+            m2 += m2t + d * d * (n * nt / tot);
+            n = tot;
+        }
+    }
+    sn[ty][tx] = n; sm[ty][tx] = mean; sq[ty][tx] = m2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int l = 1; l < 16; ++l) {
+            float nt = sn[l][tx];
+            if (nt > 0.f) {
+                float tot = n + nt, d = sm[l][tx] - mean;
+                mean += d * (nt / tot);
+                m2 += sq[l][tx] + d * d * (n * nt / tot);
+                n = tot;
+            }
+        }
+        float var = m2 / n;
+        float inv = rsqrtf(var + eps);
+        mean_out[c] = mean; invstd_out[c] = inv;
+        float g = gamma[c] * inv;
+        scale[c] = g; shift[c] = beta[c] - mean * g;
+        if (rmean) {
+            float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+        }
+    }
+}
+
+// eval mode: scale/shift straight from the running statistics
+__global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                            float eps, int C, float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        float g = gamma[c] * rsqrtf(rvar[c] + eps);
+        scale[c] = g; shift[c] = beta[c] - rmean[c] * g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: z = act(y*scale[c] + shift[c] [+ residual])
+// ---------------------------------------------------------------------------------------------
+template <bool RELU, bool RES>
+__global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const bf16_t* __restrict__ res,
+                                                          bf16_t* __restrict__ z, long long nchunks, int cchunks) {
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        int c = (int)(i % cchunks) * 8;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(y + (i << 3));
+        float sc[8], sh[8];
+        load8f(scale + c, sc); load8f(shift + c, sh);
+        bf16x8 r;
+        if (RES) r = *reinterpret_cast<const bf16x8*>(res + (i << 3));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = bf2f(v[e]) * sc[e] + sh[e];
+            if (RES) f += bf2f(r[e]);
+            if (RELU) f = fmaxf(f, 0.f);
+            o[e] = f2bf(f);
+        }
+        *reinterpret_cast<bf16x8*>(z + (i << 3)) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8a: per-block partial sums  s1[c] = sum g,  s2[c] = sum g*y,  g = dz * (z > 0) (RELU) or dz.
+// grid = G blocks over contiguous row ranges; 256 threads = C/8 chunk columns x row lanes.
+// ---------------------------------------------------------------------------------------------
+template <bool RELU>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
+                                                           const bf16_t* __restrict__ z, float* __restrict__ partial,
+                                                           long long M, int C, long long rows_per_block) {
+    __shared__ float red[2][2048];
+    const int cchunks = C >> 3, rlanes = 256 / cchunks;
+    const int cc = threadIdx.x % cchunks, rl = threadIdx.x / cchunks;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (long long r = r0 + rl; r < r1; r += rlanes) {
+        long long o = r * C + cc * 8;
+        bf16x8 d = *reinterpret_cast<const bf16x8*>(dz + o);
+        bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + o);
+        bf16x8 zv;
+        if (RELU) zv = *reinterpret_cast<const bf16x8*>(z + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float g = bf2f(d[e]);
+            if (RELU) g = bf2f(zv[e]) > 0.f ? g : 0.f;
+            s1[e] += g; s2[e] += g * bf2f(yv[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x * 8 + e] = s1[e]; red[1][threadIdx.x * 8 + e] = s2[e]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        int which = t / C, c = t - which * C;
+        float acc = 0.f;
+        for (int l = 0; l < rlanes; ++l) acc += red[which][(l * cchunks + (c >> 3)) * 8 + (c & 7)];
+        partial[((long long)blockIdx.x * 2 + which) * C + c] = acc;
+    }
+}
+
+// K8b: dgamma = invstd*(s2 - mean*s1), dbeta = s1, and the per-channel coefficients of
+// dy = ca*g + cb*y + cc  (ca = gamma*invstd, cb = -ca*invstd*dgamma/M, cc = -ca*s1/M - cb*mean)
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, int C, long long M,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/) {
+    __shared__ float a1[16][64], a2[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (int t = ty; t < G; t += 16) {
+            s1 += partial[((long long)t * 2) * C + c];
+            s2 += partial[((long long)t * 2 + 1) * C + c];
+        }
+    a1[ty][tx] = s1; a2[ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int l = 1; l < 16; ++l) { s1 += a1[l][tx]; s2 += a2[l][tx]; }
+        float mu = mean[c], inv = invstd[c];
+        float dg = inv * (s2 - mu * s1);
+        dgamma[c] = dg; dbeta[c] = s1;
+        float invM = 1.f / (float)M;
+        float ca = gamma[c] * inv;
+        float cb = -ca * inv * dg * invM;
+        coef[c] = ca; coef[C + c] = cb; coef[2 * C + c] = -ca * s1 * invM - cb * mu;
+    }
+}
+
+// K8c: dy = ca*g + cb*y + cc ; optionally also store g (gradient of the residual branch)
+template <bool RELU, bool WRITE_G>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
+                                                          const bf16_t* __restrict__ z, const float* __restrict__ coef,
+                                                          bf16_t* __restrict__ dy, bf16_t* __restrict__ gout,
+                                                          long long nchunks, int cchunks) {
+    const int C = cchunks * 8;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        int c = (int)(i % cchunks) * 8;
+        bf16x8 d = *reinterpret_cast<const bf16x8*>(dz + (i << 3));
+        bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + (i << 3));
+        bf16x8 zv;
+        if (RELU) zv = *reinterpret_cast<const bf16x8*>(z + (i << 3));
+        float ca[8], cb[8], c0[8];
+        load8f(coef + c, ca); load8f(coef + C + c, cb); load8f(coef + 2 * C + c, c0);
+        bf16x8 o, go;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float g = bf2f(d[e]);
+            if (RELU) g = bf2f(zv[e]) > 0.f ? g : 0.f;
+            o[e] = f2bf(ca[e] * g + cb[e] * bf2f(yv[e]) + c0[e]);
+            if (WRITE_G) go[e] = f2bf(g);
+        }
+        *reinterpret_cast<bf16x8*>(dy + (i << 3)) = o;
+        if (WRITE_G) *reinterpret_cast<bf16x8*>(gout + (i << 3)) = go;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10: 3x3 / stride 2 / pad 1 max pooling, NHWC.  Forward keeps the winning tap (0..8, first
+// maximum in scan order like torch) as one byte per element; backward gathers.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                         unsigned char* __restrict__ idx, int B, int H, int W, int C,
+                                                         int Ho, int Wo) {
+    const int cchunks = C >> 3;
+    long long total = (long long)B * Ho * Wo * cchunks;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int cc = (int)(i % cchunks);
+        long long pix = i / cchunks;
+        int wo = (int)(pix % Wo);
+        long long t = pix / Wo;
+        int ho = (int)(t % Ho), b = (int)(t / Ho);
+        float best[8];
+        unsigned char bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -3.0e38f; bi[e] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s;
+                if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((long long)b * H + hi) * W + wi) * C + cc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f(v[e]);
+                    if (first || f > best[e]) { best[e] = f; bi[e] = (unsigned char)(r * 3 + s); }
+                }
+                first = false;
+            }
+        bf16x8 o;
+        u32x2 packed = {0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = f2bf(best[e]);
+            packed[e >> 2] |= (unsigned)bi[e] << (8 * (e & 3));
+        }
+        *reinterpret_cast<bf16x8*>(out + (i << 3)) = o;
+        if (idx) *reinterpret_cast<u32x2*>(idx + (i << 3)) = packed;
+    }
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                         bf16_t* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+    const int cchunks = C >> 3;
+    long long total = (long long)B * H * W * cchunks;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int cc = (int)(i % cchunks);
+        long long pix = i / cchunks;
+        int wi = (int)(pix % W);
+        long long t = pix / W;
+        int hi = (int)(t % H), b = (int)(t / H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;   // windows ho with ho*2-1 <= hi <= ho*2+1
+        int wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            if (ho >= Ho) continue;
+            int r = hi - (ho * 2 - 1);
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                if (wo >= Wo) continue;
+                int s = wi - (wo * 2 - 1);
+                unsigned tap = (unsigned)(r * 3 + s);
+                long long o = ((((long long)b * Ho + ho) * Wo + wo) * cchunks + cc) << 3;
+                u32x2 pk = *reinterpret_cast<const u32x2*>(idx + o);
+                bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    unsigned w = (pk[e >> 2] >> (8 * (e & 3))) & 0xffu;
+                    if (w == tap) acc[e] += bf2f(d[e]);
+                }
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+        *reinterpret_cast<bf16x8*>(dx + (i << 3)) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K11: global average pool [B,HW,C] -> [B,C] and its gradient
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int HW, int C) {
+    const int cchunks = C >> 3;
+    long long total = (long long)B * cchunks;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int cc = (int)(i % cchunks);
+    long long b = i / cchunks;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const bf16_t* p = x + b * HW * C + cc * 8;
+    for (int k = 0; k < HW; ++k) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(p + (long long)k * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+    }
+    float inv = 1.f / (float)HW;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] * inv);
+    *reinterpret_cast<bf16x8*>(out + (i << 3)) = o;
+}
+
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int HW, int C) {
+    const int cchunks = C >> 3;
+    long long total = (long long)B * HW * cchunks;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    float inv = 1.f / (float)HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int cc = (int)(i % cchunks);
+        long long b = i / ((long long)cchunks * HW);
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (b * cchunks + cc) * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(v[e]) * inv);
+        *reinterpret_cast<bf16x8*>(dx + (i << 3)) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K13: softmax cross-entropy, one wave per row.  loss_rows[b] = logsumexp - logit[label];
+// dlogits[b][n] = (softmax - onehot) * grad_scale, written with row stride ldd (columns N..ldd-1
+// zero-filled so the padded tensor can feed the dense wgrad/dgrad GEMMs directly).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_xent_kernel(const bf16_t* __restrict__ logits, const long long* __restrict__ labels,
+                                                          float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits,
+                                                          int B, int N, int ldl, int ldd, float grad_scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const bf16_t* lp = logits + (long long)row * ldl;
+    float mx = -3.0e38f;
+    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, bf2f(lp[n]));
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int n = lane; n < N; n += 64) sum += __expf(bf2f(lp[n]) - mx);
+    sum = wave_sum(sum);
+    const int label = (int)labels[row];
+    const float lse = mx + __logf(sum);
+    if (lane == 0) loss_rows[row] = (label >= 0 && label < N) ? lse - bf2f(lp[label]) : 0.f;
+    if (dlogits) {
+        bf16_t* dp = dlogits + (long long)row * ldd;
+        const float inv = 1.f / sum;
+        for (int n = lane; n < ldd; n += 64) {
+            float g = 0.f;
+            if (n < N) g = (__expf(bf2f(lp[n]) - mx) * inv - (n == label ? 1.f : 0.f)) * grad_scale;
+            dp[n] = f2bf(g);
+        }
+    }
+}
+
+// y[m][n] += bias[n]
+__global__ void __launch_bounds__(256) bias_add_kernel(bf16_t* __restrict__ y, const float* __restrict__ bias, long long nchunks, int cchunks) {
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        int c = (int)(i % cchunks) * 8;
+        bf16x8 v = *reinterpret_cast<bf16x8*>(y + (i << 3));
+        float b[8];
+        load8f(bias + c, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + b[e]);
+        *reinterpret_cast<bf16x8*>(y + (i << 3)) = v;
+    }
+}
+
+// column sums of a bf16 [M][ld] matrix (first N columns) into fp32 — dense-layer bias gradient
+__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ a, float* __restrict__ out, int M, int N, int ld) {
+    int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += bf2f(a[(long long)m * ld + n]);
+    out[n] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight flip-transpose for backward-data, many tensors per launch:
+//   dst[c][R-1-r][S-1-s][k] = src[k][r][s][c]   (k padded with zeros up to Kpad)
+// One block moves a 32(k) x 32(c) tile of one tap through LDS.
+// ---------------------------------------------------------------------------------------------
+struct WtEntry { long long src, dst; int K, R, S, C, Kpad, block0; };
+
+__global__ void __launch_bounds__(256) weight_flip_transpose_kernel(const bf16_t* __restrict__ base_src, bf16_t* __restrict__ base_dst,
+                                                                   const WtEntry* __restrict__ table, int nentries) {
+    __shared__ bf16_t tile[32][34];
+    int lo = 0, hi = nentries - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (table[mid].block0 <= bid) lo = mid; else hi = mid - 1;
+    }
+    const WtEntry e = table[lo];
+    int t = bid - e.block0;
+    const int ct = (e.C + 31) / 32, kt = (e.Kpad + 31) / 32;
+    const int tc = t % ct; t /= ct;
+    const int tk = t % kt; t /= kt;
+    const int s = t % e.S, r = t / e.S;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bf16_t* src = base_src + e.src;
+    bf16_t* dst = base_dst + e.dst;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int k = tk * 32 + ty + i * 8, c = tc * 32 + tx;
+        bf16_t v = f2bf(0.f);
+        if (k < e.K && c < e.C) v = src[(((long long)k * e.R + r) * e.S + s) * e.C + c];
+        tile[ty + i * 8][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tc * 32 + ty + i * 8, k = tk * 32 + tx;
+        if (c < e.C && k < e.Kpad)
+            dst[(((long long)c * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)) * e.Kpad + k] = tile[tx][ty + i * 8];
+    }
+}
+
+// Stem input packing: NHWC (C <= 4) bf16 -> [B][H][W + 8][4] with 3 zero pixels on the left, 5 on
+// the right and zero-filled extra channels, so one filter row of the 7x7/2 stem conv is one
+// contiguous, 16-byte-aligned 64-byte run (8 taps x 4 channels) for every output column.
+__global__ void __launch_bounds__(256) stem_pack_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int B, int H,
+                                                       int W, int C, long long xs_b, long long xs_h, long long xs_w,
+                                                       long long xs_c) {
+    const int Wp = W + 8;
+    long long total = (long long)B * H * Wp;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int wp = (int)(i % Wp);
+        long long row = i / Wp;
+        int wi = wp - 3;
+        bf16x4 v = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+        if (wi >= 0 && wi < W) {
+            long long b = row / H, h = row - b * H;
+            const bf16_t* p = x + b * xs_b + h * xs_h + (long long)wi * xs_w;
+            for (int c = 0; c < C; ++c) v[c] = p[c * xs_c];
+        }
+        *reinterpret_cast<bf16x4*>(out + (i << 2)) = v;
+    }
+}
+
+}  // namespace
+
+#define CHK(cond, code) do { if (!(cond)) return (code); } while (0)
+
+static inline bool pow2_chunks_ok(int C) {
+    if (C <= 0 || (C & 7)) return false;
+    int cch = C >> 3;
+    return cch <= 256 && (256 % cch) == 0;
+}
+
+extern "C" int ddl_bn_stats_partial(const void* y, void* partial, long long M, int C, int rows_per_tile, hipStream_t stream) {
+    CHK(y && partial && M > 0 && rows_per_tile > 0 && pow2_chunks_ok(C), DDL_EINVAL);
+    CHK(ddl_aligned16(y), DDL_EALIGN);
+    int T = (int)((M + rows_per_tile - 1) / rows_per_tile);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(T), dim3(256), 0, stream, (const bf16_t*)y, (float*)partial, M, C, rows_per_tile);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long M, int rows_per_tile, const void* gamma,
+                                   const void* beta, void* rmean, void* rvar, float momentum, float eps, void* mean,
+                                   void* invstd, void* scale, void* shift, hipStream_t stream) {
+    CHK(partial && gamma && beta && mean && invstd && scale && shift && T > 0 && C > 0 && M > 0, DDL_EINVAL);
+    CHK((long long)T * rows_per_tile >= M && (long long)(T - 1) * rows_per_tile < M, DDL_EINVAL);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, T, C, M,
+                       rows_per_tile, (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
+                       (float*)mean, (float*)invstd, (float*)scale, (float*)shift);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_eval_coeffs(const void* gamma, const void* beta, const void* rmean, const void* rvar, float eps, int C,
+                                  void* scale, void* shift, hipStream_t stream) {
+    CHK(gamma && beta && rmean && rvar && scale && shift && C > 0, DDL_EINVAL);
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)gamma,
+                       (const float*)beta, (const float*)rmean, (const float*)rvar, eps, C, (float*)scale, (float*)shift);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_apply_fwd(const void* y, const void* scale, const void* shift, const void* res, void* z,
+                                long long M, int C, int relu, hipStream_t stream) {
+    CHK(y && scale && shift && z && M > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
+    CHK(ddl_aligned16(y) && ddl_aligned16(z) && ddl_aligned16(scale) && ddl_aligned16(shift) && (!res || ddl_aligned16(res)), DDL_EALIGN);
+    long long nchunks = M * (C >> 3);
+    dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
+#define L(R, S) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S>), grid, block, 0, stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (bf16_t*)z, nchunks, C >> 3)
+    if (relu) { if (res) L(true, true); else L(true, false); }
+    else { if (res) L(false, true); else L(false, false); }
+#undef L
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_bwd_blocks(long long M) {
+    long long g = (M + 255) / 256;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int ddl_bn_bwd_reduce(const void* dz, const void* y, const void* z, void* partial, long long M, int C, int relu,
+                                 int G, hipStream_t stream) {
+    CHK(dz && y && partial && M > 0 && G > 0 && pow2_chunks_ok(C) && (!relu || z), DDL_EINVAL);
+    CHK(ddl_aligned16(dz) && ddl_aligned16(y) && (!z || ddl_aligned16(z)), DDL_EALIGN);
+    long long rpb = (M + G - 1) / G;
+    if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (float*)partial, M, C, rpb);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (float*)partial, M, C, rpb);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long M, const void* gamma, const void* mean,
+                                   const void* invstd, void* dgamma, void* dbeta, void* coef, hipStream_t stream) {
+    CHK(partial && gamma && mean && invstd && dgamma && dbeta && coef && G > 0 && C > 0 && M > 0, DDL_EINVAL);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, G, C, M,
+                       (const float*)gamma, (const float*)mean, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_bwd_apply(const void* dz, const void* y, const void* z, const void* coef, void* dy, void* gout,
+                                long long M, int C, int relu, hipStream_t stream) {
+    CHK(dz && y && coef && dy && M > 0 && C > 0 && (C & 7) == 0 && (!relu || z), DDL_EINVAL);
+    CHK(ddl_aligned16(dz) && ddl_aligned16(y) && ddl_aligned16(dy) && ddl_aligned16(coef) && (!z || ddl_aligned16(z)) && (!gout || ddl_aligned16(gout)) && (C % 4 == 0), DDL_EALIGN);
+    long long nchunks = M * (C >> 3);
+    dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
+#define L(R, G) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, G>), grid, block, 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
+    if (relu) { if (gout) L(true, true); else L(true, false); }
+    else { if (gout) L(false, true); else L(false, false); }
+#undef L
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_maxpool3x3s2_fwd(const void* x, void* out, void* idx, int B, int H, int W, int C, hipStream_t stream) {
+    CHK(x && out && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
+    CHK(ddl_aligned16(x) && ddl_aligned16(out) && (!idx || (reinterpret_cast<uintptr_t>(idx) & 7) == 0), DDL_EALIGN);
+    int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    long long total = (long long)B * Ho * Wo * (C >> 3);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                       (bf16_t*)out, (unsigned char*)idx, B, H, W, C, Ho, Wo);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, int B, int H, int W, int C, hipStream_t stream) {
+    CHK(dy && idx && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
+    CHK(ddl_aligned16(dy) && ddl_aligned16(dx) && (reinterpret_cast<uintptr_t>(idx) & 7) == 0, DDL_EALIGN);
+    int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    long long total = (long long)B * H * W * (C >> 3);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)dy,
+                       (const unsigned char*)idx, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_avgpool_fwd(const void* x, void* out, int B, int HW, int C, hipStream_t stream) {
+    CHK(x && out && B > 0 && HW > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
+    CHK(ddl_aligned16(x) && ddl_aligned16(out), DDL_EALIGN);
+    long long total = (long long)B * (C >> 3);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, B, HW, C);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, hipStream_t stream) {
+    CHK(dy && dx && B > 0 && HW > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
+    CHK(ddl_aligned16(dy) && ddl_aligned16(dx), DDL_EALIGN);
+    long long total = (long long)B * HW * (C >> 3);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)dy, (bf16_t*)dx, B, HW, C);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_softmax_xent(const void* logits, const void* labels, void* loss_rows, void* dlogits, int B, int N, int ldl,
+                                int ldd, float grad_scale, hipStream_t stream) {
+    CHK(logits && labels && loss_rows && B > 0 && N > 0 && ldl >= N && (!dlogits || ldd >= N), DDL_EINVAL);
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const bf16_t*)logits,
+                       (const long long*)labels, (float*)loss_rows, (bf16_t*)dlogits, B, N, ldl, ldd, grad_scale);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bias_add(void* y, const void* bias, long long M, int N, hipStream_t stream) {
+    CHK(y && bias && M > 0 && N > 0 && (N & 7) == 0, DDL_EINVAL);
+    CHK(ddl_aligned16(y) && ddl_aligned16(bias), DDL_EALIGN);
+    long long nchunks = M * (N >> 3);
+    hipLaunchKernelGGL(bias_add_kernel, dim3(ddl_stream_grid(nchunks, 256)), dim3(256), 0, stream, (bf16_t*)y, (const float*)bias, nchunks, N >> 3);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_colsum(const void* a, void* out, int M, int N, int ld, hipStream_t stream) {
+    CHK(a && out && M > 0 && N > 0 && ld >= N, DDL_EINVAL);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const bf16_t*)a, (float*)out, M, N, ld);
+    return ddl_launch_status();
+}
+
+// table entries are 6 x int64 + ... : see WtEntry; `table` is a device pointer prepared by the host
+extern "C" int ddl_weight_flip_transpose(const void* base_src, void* base_dst, const void* table, int nentries,
+                                         int total_blocks, hipStream_t stream) {
+    CHK(base_src && base_dst && table && nentries > 0 && total_blocks > 0, DDL_EINVAL);
+    hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(total_blocks), dim3(256), 0, stream, (const bf16_t*)base_src,
+                       (bf16_t*)base_dst, (const WtEntry*)table, nentries);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_wt_entry_bytes() { return (int)sizeof(WtEntry); }
+
+// x: logical [B][C][H][W] bf16 with element strides (xs_b, xs_c, xs_h, xs_w); out: [B][H][W+8][4]
+extern "C" int ddl_stem_pack(const void* x, void* out, int B, int H, int W, int C, long long xs_b, long long xs_h,
+                             long long xs_w, long long xs_c, hipStream_t stream) {
+    CHK(x && out && B > 0 && H > 0 && W > 0 && C > 0 && C <= 4, DDL_EINVAL);
+    CHK((reinterpret_cast<uintptr_t>(out) & 15) == 0, DDL_EALIGN);
+    long long total = (long long)B * H * (W + 8);
+    hipLaunchKernelGGL(stem_pack_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                       (bf16_t*)out, B, H, W, C, xs_b, xs_h, xs_w, xs_c);
+    return ddl_launch_status();
+}

@@ -86,6 +86,15 @@ class BatchNormAct(nn.Module):
         return "{channels}, relu={relu}, momentum={momentum}, eps={eps}".format(**self.__dict__)
 
 
+def _cba(conv, bn, x, residual=None):
+    """conv -> BatchNorm(+residual)(+ReLU) through the fused functional op."""
+    if bn.training:
+        bn.num_batches_tracked += 1
+    return ops.conv_bn_act(x, conv.weight, conv.stride, conv.padding, bn.weight, bn.bias,
+                           bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps,
+                           bn.relu, residual)
+
+
 class Linear(nn.Module):
     def __init__(self, cin, cout):
         super().__init__()
@@ -101,6 +110,9 @@ class _Downsample(nn.Sequential):
 
     def __init__(self, cin, cout, stride):
         super().__init__(Conv2d(cin, cout, 1, stride, 0), BatchNormAct(cout, relu=False))
+
+    def forward(self, x):
+        return _cba(self[0], self[1], x)
 
 
 class Bottleneck(nn.Module):
@@ -118,9 +130,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         shortcut = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x))
-        out = self.bn2(self.conv2(out))
-        return self.bn3(self.conv3(out), residual=shortcut)
+        out = _cba(self.conv1, self.bn1, x)
+        out = _cba(self.conv2, self.bn2, out)
+        return _cba(self.conv3, self.bn3, out, shortcut)
 
 
 class BasicBlock(nn.Module):
@@ -136,8 +148,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         shortcut = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x))
-        return self.bn2(self.conv2(out), residual=shortcut)
+        out = _cba(self.conv1, self.bn1, x)
+        return _cba(self.conv2, self.bn2, out, shortcut)
 
 
 class ResNet(nn.Module):
@@ -164,7 +176,7 @@ class ResNet(nn.Module):
         self.feature_dim = cin
 
     def forward(self, x):
-        x = self.bn1(self.conv1(x))
+        x = _cba(self.conv1, self.bn1, x)
         x = ops.maxpool3x3s2(x)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(ops.global_avgpool(x))

@@ -24,7 +24,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-__all__ = ["use_hip", "conv2d", "batchnorm_act", "maxpool3x3s2", "global_avgpool", "linear",
+__all__ = ["use_hip", "conv2d", "conv_bn_act", "batchnorm_act", "maxpool3x3s2", "global_avgpool", "linear",
            "softmax_cross_entropy", "topk_correct", "set_backend", "backend"]
 
 _FORCED = os.environ.get("DDL_OPS", "auto").lower()  # auto | hip | aten
@@ -59,8 +59,41 @@ def conv2d(x, weight, stride=1, padding=0):
     if use_hip(x):
         from . import hip_ops
 
-        return hip_ops.conv2d(x, weight, stride, padding)
+        if hip_ops.conv_supported(weight, stride, padding):
+            return hip_ops.conv2d(x, weight, stride, padding)
+        _warn_once("conv2d", "Cin=%d Cout=%d %dx%d" % (weight.shape[1], weight.shape[0],
+                                                        weight.shape[2], weight.shape[3]))
     return F.conv2d(x, weight.to(x.dtype), None, stride, padding)
+
+
+_warned = set()
+
+
+def _warn_once(op, what):
+    """Shapes outside the HIP kernels' envelope run on ATen — loudly, never silently."""
+    key = (op, what)
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+
+        warnings.warn("ops.%s: no HIP kernel for %s; using the ATen implementation" % (op, what))
+
+
+def conv_bn_act(x, weight, stride, padding, gamma, beta, running_mean, running_var, training,
+                momentum=0.1, eps=1e-5, relu=True, residual=None):
+    """``act(bn(conv(x)) [+ residual])`` — on the HIP path the convolution's epilogue emits the
+    per-channel batch-statistic partial sums, so BatchNorm never re-reads the conv output to
+    compute them (SURVEY §2.6 K1 note / K6)."""
+    if use_hip(x):
+        from . import hip_ops
+
+        if hip_ops.conv_supported(weight, stride, padding) and hip_ops.bn_supported(weight.shape[0]):
+            y, stats = hip_ops.conv2d_stats(x, weight, stride, padding, bool(training))
+            return hip_ops.batchnorm_act(y, gamma, beta, running_mean, running_var, training,
+                                         momentum, eps, relu, residual, stats)
+    y = conv2d(x, weight, stride, padding)
+    return batchnorm_act(y, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
+                         residual)
 
 
 def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
@@ -70,8 +103,10 @@ def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum=
     if use_hip(x):
         from . import hip_ops
 
-        return hip_ops.batchnorm_act(x, gamma, beta, running_mean, running_var, training,
-                                     momentum, eps, relu, residual)
+        if hip_ops.bn_supported(x.shape[1]):
+            return hip_ops.batchnorm_act(x, gamma, beta, running_mean, running_var, training,
+                                         momentum, eps, relu, residual)
+        _warn_once("batchnorm_act", "C=%d" % x.shape[1])
     y = F.batch_norm(x.float() if x.dtype != torch.float32 and not x.is_cuda else x,
                      running_mean, running_var, gamma, beta, training, momentum, eps)
     y = y.to(x.dtype)
@@ -101,7 +136,9 @@ def linear(x, weight, bias=None):
     if use_hip(x):
         from . import hip_ops
 
-        return hip_ops.linear(x, weight, bias)
+        if x.dim() == 2 and hip_ops.linear_supported(weight):
+            return hip_ops.linear(x, weight, bias)
+        _warn_once("linear", "in=%d out=%d" % (weight.shape[1], weight.shape[0]))
     return F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
 
 

@@ -1,40 +1,475 @@
 """autograd wrappers around the HIP kernels (GPU path of ``ops.functional``).
 
-Ops whose hand-written kernel has not landed yet call the ATen op explicitly here — never as
-a hidden fallback: ``IMPLEMENTED`` lists which ops run on our own kernels, and
-``tests/test_gpu_kernels.py`` asserts the flagship path uses them.
+Every op here runs on the hand-written gfx950 kernels of ``csrc/kernels`` (SURVEY §2.6
+K1–K13): implicit-GEMM convolution forward / backward-data / backward-weights on bf16 MFMA,
+BatchNorm statistics fused into the conv epilogue, fused BN-apply(+residual)+ReLU forward and
+backward, pooling, the dense head and softmax cross-entropy.  Tensors are logically NCHW and
+physically NHWC (``torch.channels_last``) bf16; BatchNorm parameters and statistics are fp32.
+
+Replaces what the reference gets from cuDNN/ATen through torchvision's ResNet-50
+(``HorovodPytorch/src/imagenet_pytorch_horovod.py:214-217,323,340``).
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
-import torch.nn.functional as F
+from torch.autograd import Function
 
-IMPLEMENTED = set()
+from . import kernels as K
+
+IMPLEMENTED = {"conv2d", "batchnorm_act", "maxpool3x3s2", "global_avgpool", "linear",
+               "softmax_cross_entropy"}
+
+_BF16 = torch.bfloat16
+_CL = torch.channels_last
+
+
+def _empty_nhwc(B, C, H, W, device, dtype=_BF16):
+    return torch.empty((B, C, H, W), dtype=dtype, device=device, memory_format=_CL)
+
+
+def _as_nhwc(t):
+    if t.dim() == 4 and (t.stride(1) == 1 or t.shape[1] == 1) and \
+            t.is_contiguous(memory_format=_CL):
+        return t
+    return t.contiguous(memory_format=_CL)
+
+
+def _geom(x):
+    B, C, H, W, sb, sh, sw = K.nhwc_dims(x)
+    return (B, H, W, C, sb, sh, sw, K.storage_numel_from(x))
+
+
+def _krsc_ok(w):
+    """conv weight [K, C, R, S] whose memory is dense [K][R][S][C]."""
+    if w.dim() == 2:
+        return w.is_contiguous()
+    return w.permute(0, 2, 3, 1).is_contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# flipped / transposed weights for backward-data: dst[c][R-1-r][S-1-s][k] = w[k][r][s][c]
+# All registered weights are refreshed by ONE kernel launch per optimizer step.
+# ----------------------------------------------------------------------------------------------
+class _WeightTransposes:
+    _DT = np.dtype([("src", "<i8"), ("dst", "<i8"), ("K", "<i4"), ("R", "<i4"), ("S", "<i4"),
+                    ("C", "<i4"), ("Kpad", "<i4"), ("block0", "<i4")])
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.entries = {}
+        self.dirty = True
+        self.epoch = 0
+        self.done_epoch = -1
+        self.table = None
+        self.dst = None
+        self.total_blocks = 0
+        self.base_src = 0
+
+    def bump(self):
+        self.epoch += 1
+
+    def _register(self, w):
+        if w.dim() == 4:
+            Kc, C, R, S = w.shape
+        else:
+            (Kc, C), R, S = w.shape, 1, 1
+        kpad = (Kc + 31) // 32 * 32
+        self.entries[id(w)] = {"w": w, "ptr": w.data_ptr(), "K": Kc, "C": C, "R": R, "S": S,
+                               "Kpad": kpad, "version": -1, "dst_off": 0}
+        self.dirty = True
+
+    def _rebuild(self, device):
+        assert K.lib().ddl_wt_entry_bytes() == self._DT.itemsize
+        # drop entries whose tensor storage moved or died
+        live = {k: e for k, e in self.entries.items() if e["w"].data_ptr() == e["ptr"]}
+        self.entries = live
+        ents = list(live.values())
+        self.base_src = min(e["ptr"] for e in ents)
+        tab = np.zeros(len(ents), dtype=self._DT)
+        off = blocks = 0
+        for i, e in enumerate(ents):
+            e["dst_off"] = off
+            nb = ((e["Kpad"] + 31) // 32) * ((e["C"] + 31) // 32) * e["R"] * e["S"]
+            tab[i] = ((e["ptr"] - self.base_src) // 2, off, e["K"], e["R"], e["S"], e["C"],
+                      e["Kpad"], blocks)
+            blocks += nb
+            off += (e["C"] * e["R"] * e["S"] * e["Kpad"] + 7) // 8 * 8
+        self.total_blocks = blocks
+        self.dst = torch.empty(off, dtype=_BF16, device=device)
+        self.table = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+        self.n = len(ents)
+        self.dirty = False
+
+    def get(self, w):
+        e = self.entries.get(id(w))
+        if e is None or e["ptr"] != w.data_ptr():
+            self._register(w)
+            e = self.entries[id(w)]
+        stale = self.dirty or self.done_epoch != self.epoch or e["version"] != w._version
+        if self.dirty:
+            self._rebuild(w.device)
+        if stale:
+            K.weight_flip_transpose(self.base_src, self.dst.data_ptr(), self.table, self.n,
+                                    self.total_blocks)
+            for x in self.entries.values():
+                x["version"] = x["w"]._version
+            self.done_epoch = self.epoch
+        n = e["C"] * e["R"] * e["S"] * e["Kpad"]
+        return self.dst[e["dst_off"]: e["dst_off"] + n]
+
+
+_WT = _WeightTransposes()
+
+
+def weights_changed():
+    """Tell the transposed-weight cache that parameters were updated outside autograd's view
+    (the fused optimizers write them through raw pointers)."""
+    _WT.bump()
+
+
+def reset_caches():
+    _WT.reset()
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------
+def _is_stem(w, stride, padding):
+    return w.dim() == 4 and w.shape[1] <= 4 and w.shape[2] == 7 and w.shape[3] == 7 and \
+        stride == 2 and padding == 3
+
+
+def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho, Wo, n_valid=None):
+    """Backward-weights: split-K partials then ordered reduction into a tensor shaped like
+    ``w_like`` (memory [K][R][S][C])."""
+    B, Hin, Win, C = geom[0], geom[1], geom[2], geom[3]
+    M = B * Ho * Wo
+    splits = K.conv_wgrad_splits(M, Kc, C, R, S)
+    slab = Kc * R * S * C
+    partial = torch.empty((splits, slab), dtype=torch.float32, device=dy.device)
+    K.conv_wgrad(dy, x_ptr_tensor, geom, partial, Kc, R, S, stride, pad, pad_w, Ho, Wo, splits)
+    n = slab if n_valid is None else n_valid
+    K.splitk_reduce(partial, w_like, n, splits, slab)
+    return w_like
+
+
+class ConvFn(Function):
+    """y = conv2d(x, w) (no bias); optionally also the per-tile BatchNorm partial sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding, want_stats):
+        x = _as_nhwc(x)
+        if not _krsc_ok(w):
+            raise K.KernelError("conv weight must be channels_last (KRSC) in memory")
+        B, C, H, W = x.shape
+        Kc, Cw, R, S = w.shape
+        if Cw != C:
+            raise K.KernelError("conv: input has %d channels, weight expects %d" % (C, Cw))
+        Ho = (H + 2 * padding - R) // stride + 1
+        Wo = (W + 2 * padding - S) // stride + 1
+        y = _empty_nhwc(B, Kc, Ho, Wo, x.device)
+        stats = None
+        if want_stats:
+            stats = torch.empty((K.conv_tiles_m(B * Ho * Wo), 2, Kc), dtype=torch.float32,
+                                device=x.device)
+        K.conv_igemm(x, _geom(x), w, y, Kc, R, S, stride, padding, padding, 1, Ho, Wo, stats=stats)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding)
+        if stats is None:
+            stats = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        x, w = ctx.saved_tensors
+        stride, padding = ctx.cfg
+        dy = _as_nhwc(dy)
+        B, C, H, W = x.shape
+        Kc, _, R, S = w.shape
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = _WT.get(w)
+            dx = _empty_nhwc(B, C, H, W, x.device)
+            K.conv_igemm(dy, _geom(dy), wt, dx, C, R, S, 1, R - 1 - padding, S - 1 - padding,
+                         stride, H, W)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad_into(dy, x, _geom(x), torch.empty_like(w), Kc, R, S, stride, padding,
+                             padding, Ho, Wo)
+        return dx, dw, None, None, None
+
+
+class StemConvFn(Function):
+    """7x7 / stride 2 / pad 3 convolution of a 3-channel image (K5).  The image is repacked to a
+    W-padded NHWC4 layout so that each filter row is one contiguous 32-element run; the conv
+    then runs on the common implicit-GEMM kernel with R = 7 "taps" of 32 channels."""
+
+    @staticmethod
+    def forward(ctx, x, w, want_stats):
+        if x.dtype != _BF16:
+            x = x.to(_BF16)
+        B, C, H, W = x.shape
+        Kc = w.shape[0]
+        xp = torch.empty((B, H, W + 8, 4), dtype=_BF16, device=x.device)
+        K.stem_pack(x, xp)
+        wp = torch.zeros((Kc, 7, 8, 4), dtype=_BF16, device=x.device)
+        wp[:, :, :7, :C] = w.permute(0, 2, 3, 1)
+        Ho = (H + 6 - 7) // 2 + 1
+        Wo = (W + 6 - 7) // 2 + 1
+        geom = (B, H, W + 1, 32, H * (W + 8) * 4, (W + 8) * 4, 4, xp.numel())
+        y = _empty_nhwc(B, Kc, Ho, Wo, x.device)
+        stats = None
+        if want_stats:
+            stats = torch.empty((K.conv_tiles_m(B * Ho * Wo), 2, Kc), dtype=torch.float32,
+                                device=x.device)
+        K.conv_igemm(xp, geom, wp, y, Kc, 7, 1, 2, 3, 0, 1, Ho, Wo, stats=stats)
+        ctx.save_for_backward(xp, w)
+        ctx.geom = geom
+        ctx.cin = C
+        if stats is None:
+            stats = torch.empty(0, device=x.device)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        xp, w = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise K.KernelError("the stem convolution does not provide a gradient for its input")
+        dy = _as_nhwc(dy)
+        Kc = w.shape[0]
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        dwp = torch.empty((Kc, 7, 8, 4), dtype=torch.float32, device=dy.device)
+        _wgrad_into(dy, xp, ctx.geom, dwp, Kc, 7, 1, 2, 3, 0, Ho, Wo)
+        dw = torch.empty_like(w)
+        dw.copy_(dwp[:, :, :7, :ctx.cin].permute(0, 3, 1, 2))
+        return None, dw, None
+
+
+def conv2d_stats(x, weight, stride, padding, want_stats):
+    """(y, stats) where stats is the [tiles, 2, Cout] partial-sum tensor (or None)."""
+    if _is_stem(weight, stride, padding):
+        y, st = StemConvFn.apply(x, weight, want_stats)
+    else:
+        C = weight.shape[1]
+        if C % 32 != 0 or weight.shape[0] % 32 != 0:
+            raise K.KernelError("conv2d HIP kernel needs Cin %% 32 == 0 and Cout %% 32 == 0 "
+                                "(got Cin=%d, Cout=%d)" % (C, weight.shape[0]))
+        y, st = ConvFn.apply(x, weight, stride, padding, want_stats)
+    return y, (st if want_stats else None)
+
+
+def conv_supported(weight, stride, padding):
+    if _is_stem(weight, stride, padding):
+        return True
+    return weight.shape[1] % 32 == 0 and weight.shape[0] % 32 == 0
 
 
 def conv2d(x, weight, stride, padding):
-    return F.conv2d(x, weight, None, stride, padding)
+    return conv2d_stats(x, weight, stride, padding, False)[0]
+
+
+# ----------------------------------------------------------------------------------------------
+# batch norm (+ residual) (+ ReLU)
+# ----------------------------------------------------------------------------------------------
+def bn_supported(C):
+    return C % 8 == 0 and C // 8 <= 256 and 256 % (C // 8) == 0
+
+
+class BatchNormActFn(Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, stats, rmean, rvar, training, momentum, eps, relu):
+        y = _as_nhwc(y)
+        B, C, H, W = y.shape
+        M = B * H * W
+        dev = y.device
+        coeffs = torch.empty((4, C), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        if training:
+            if stats is None or stats.numel() == 0:
+                rows = 512
+                T = (M + rows - 1) // rows
+                stats = torch.empty((T, 2, C), dtype=torch.float32, device=dev)
+                K.bn_stats_partial(y, stats, M, C, rows)
+            else:
+                rows, T = 128, stats.shape[0]
+            K.bn_fwd_finalize(stats, T, C, M, rows, gamma, beta, rmean, rvar, momentum, eps,
+                              coeffs[0], coeffs[1], coeffs[2], coeffs[3])
+        else:
+            K.bn_eval_coeffs(gamma, beta, rmean, rvar, eps, coeffs[2], coeffs[3])
+        if residual is not None:
+            residual = _as_nhwc(residual)
+        z = torch.empty_like(y)
+        K.bn_apply_fwd(y, coeffs[2], coeffs[3], residual, z, M, C, relu)
+        ctx.relu = bool(relu)
+        ctx.training = bool(training)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(y, z if relu else None, gamma, coeffs)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if not ctx.training:
+            raise K.KernelError("BatchNorm backward in eval mode is not supported by the HIP path")
+        y, z, gamma, coeffs = ctx.saved_tensors
+        dz = _as_nhwc(dz)
+        B, C, H, W = y.shape
+        M = B * H * W
+        dev = y.device
+        G = K.bn_bwd_blocks(M)
+        partial = torch.empty((G, 2, C), dtype=torch.float32, device=dev)
+        K.bn_bwd_reduce(dz, y, z, partial, M, C, ctx.relu, G)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+        K.bn_bwd_finalize(partial, G, C, M, gamma, coeffs[0], coeffs[1], dgb[0], dgb[1], coef)
+        dy = torch.empty_like(y)
+        gres = None
+        want_res = ctx.has_res and ctx.needs_input_grad[3]
+        if want_res and ctx.relu:
+            gres = torch.empty_like(y)
+        K.bn_bwd_apply(dz, y, z, coef, dy, gres, M, C, ctx.relu)
+        if want_res and not ctx.relu:
+            gres = dz
+        return dy, dgb[0], dgb[1], gres, None, None, None, None, None, None, None
 
 
 def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
-                  residual):
-    y = F.batch_norm(x, running_mean, running_var, gamma, beta, training, momentum, eps)
-    if residual is not None:
-        y = y + residual
-    return F.relu(y) if relu else y
+                  residual, stats=None):
+    return BatchNormActFn.apply(x, gamma, beta, residual, stats, running_mean, running_var,
+                                training, momentum, eps, relu)
+
+
+# ----------------------------------------------------------------------------------------------
+# pooling
+# ----------------------------------------------------------------------------------------------
+class MaxPool3x3s2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _as_nhwc(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = _empty_nhwc(B, C, Ho, Wo, x.device)
+        idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+        K.maxpool_fwd(x, out, idx, B, H, W, C)
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        dy = _as_nhwc(dy)
+        dx = _empty_nhwc(B, C, H, W, dy.device)
+        K.maxpool_bwd(dy, idx, dx, B, H, W, C)
+        return dx
 
 
 def maxpool3x3s2(x):
-    return F.max_pool2d(x, 3, 2, 1)
+    return MaxPool3x3s2Fn.apply(x)
+
+
+class GlobalAvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _as_nhwc(x)
+        B, C, H, W = x.shape
+        out = torch.empty((B, C), dtype=_BF16, device=x.device)
+        K.avgpool_fwd(x, out, B, H * W, C)
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = dy.contiguous()
+        dx = _empty_nhwc(B, C, H, W, dy.device)
+        K.avgpool_bwd(dy, dx, B, H * W, C)
+        return dx
 
 
 def global_avgpool(x):
-    return x.mean(dim=(2, 3))
+    return GlobalAvgPoolFn.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# dense head
+# ----------------------------------------------------------------------------------------------
+def linear_supported(weight):
+    return weight.shape[1] % 32 == 0 and weight.shape[0] % 8 == 0
+
+
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        B, C = x.shape
+        N = w.shape[0]
+        y = torch.empty((B, N), dtype=_BF16, device=x.device)
+        geom = (B, 1, 1, C, C, C, C, x.numel())
+        K.conv_igemm(x, geom, w, y, N, 1, 1, 1, 0, 0, 1, 1, 1)
+        if bias is not None:
+            K.bias_add_(y, bias, B, N)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, C = x.shape
+        N = w.shape[0]
+        npad = (N + 31) // 32 * 32
+        dy = dy.contiguous()
+        if npad != N:
+            dyp = torch.zeros((B, npad), dtype=_BF16, device=dy.device)
+            dyp[:, :N] = dy
+        else:
+            dyp = dy
+        dx = dw = db = None
+        gy = (B, 1, 1, npad, npad, npad, npad, dyp.numel())
+        if ctx.needs_input_grad[0]:
+            wt = _WT.get(w)
+            dx = torch.empty((B, C), dtype=_BF16, device=dy.device)
+            K.conv_igemm(dyp, gy, wt, dx, C, 1, 1, 1, 0, 0, 1, 1, 1)
+        if ctx.needs_input_grad[1]:
+            gx = (B, 1, 1, C, C, C, C, x.numel())
+            dw = _wgrad_into(dyp, x, gx, torch.empty_like(w), npad, 1, 1, 1, 0, 0, 1, 1,
+                             n_valid=N * C)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, dtype=torch.float32, device=dy.device)
+            K.colsum(dy, db, B, N, N)
+        return dx, dw, db
 
 
 def linear(x, weight, bias):
-    return F.linear(x, weight, None if bias is None else bias.to(x.dtype))
+    return LinearFn.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# loss
+# ----------------------------------------------------------------------------------------------
+class SoftmaxCrossEntropyFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = logits.contiguous()
+        if logits.dtype != _BF16:
+            logits = logits.to(_BF16)
+        B, N = logits.shape
+        loss_rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty((B, N), dtype=_BF16, device=logits.device)
+        K.softmax_xent(logits, target.contiguous(), loss_rows, dlogits, B, N, N, N, 1.0 / B)
+        ctx.save_for_backward(dlogits)
+        return loss_rows.mean()
+
+    @staticmethod
+    def backward(ctx, go):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * go.to(dlogits.dtype), None
 
 
 def softmax_cross_entropy(logits, target):
-    return F.cross_entropy(logits.float(), target)
+    return SoftmaxCrossEntropyFn.apply(logits, target)

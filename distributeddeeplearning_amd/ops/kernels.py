@@ -129,3 +129,150 @@ def nchw_to_nhwc_normalize(x, mean=None, sd=None, in_scale=1.0):
                                       ctypes.c_int(W), ctypes.c_int(kind), _f32(in_scale), m, s,
                                       stream()), "nchw_to_nhwc_norm")
     return out.permute(0, 3, 1, 2)
+
+
+# ---- convolution / GEMM (csrc/kernels/conv_igemm.hip, conv_wgrad.hip) ------------------------
+def _i32(v):
+    return ctypes.c_int(int(v))
+
+
+def nhwc_dims(x):
+    """(B, C, H, W, stride_b, stride_h, stride_w) of a logically-NCHW tensor stored NHWC."""
+    assert x.dim() == 4
+    B, C, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    if C != 1 and sc != 1:
+        raise KernelError("tensor is not channels_last (NHWC) in memory: shape %s stride %s"
+                          % (tuple(x.shape), tuple(x.stride())))
+    if H == 1 and W == 1:
+        sh = sw = C  # degenerate spatial dims carry arbitrary strides
+    return B, C, H, W, sb, sh, sw
+
+
+def storage_numel_from(x):
+    """Elements from x's first element to the end of its allocation (buffer range for loads)."""
+    st = x.untyped_storage()
+    return (st.nbytes() - x.storage_offset() * x.element_size()) // x.element_size()
+
+
+def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil, Hout, Wout,
+               addend=None, stats=None):
+    """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel)."""
+    B, Hin, Win, C, sb, sh, sw, xn = geom
+    check(lib().ddl_conv_igemm(ptr(x_ptr_tensor), ptr(w), ptr(y), ptr(addend), ptr(stats),
+                               _i64(xn), _i64(w.numel()), _i32(B), _i32(Hin), _i32(Win), _i32(C),
+                               _i64(sb), _i64(sh), _i64(sw), _i32(Hout), _i32(Wout), _i32(n_out),
+                               _i32(R), _i32(S), _i32(ostride), _i32(pad), _i32(pad_w), _i32(idil),
+                               stream()), "conv_igemm")
+
+
+def conv_tiles_m(M):
+    return int(lib().ddl_conv_igemm_tiles_m(_i64(M)))
+
+
+def conv_wgrad_splits(M, K, C, R, S):
+    return int(lib().ddl_conv_wgrad_splits(_i64(M), _i32(K), _i32(C), _i32(R), _i32(S)))
+
+
+def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hout, Wout, splits):
+    B, Hin, Win, C, sb, sh, sw, xn = geom
+    check(lib().ddl_conv_wgrad(ptr(dy), ptr(x_ptr_tensor), ptr(partial), _i64(dy.numel()), _i64(xn),
+                               _i32(B), _i32(Hin), _i32(Win), _i32(C), _i64(sb), _i64(sh), _i64(sw),
+                               _i32(Hout), _i32(Wout), _i32(K), _i32(R), _i32(S), _i32(stride),
+                               _i32(pad), _i32(pad_w), _i32(splits), stream()), "conv_wgrad")
+
+
+def splitk_reduce(partial, out, n, splits, slab, accumulate=False):
+    check(lib().ddl_splitk_reduce(ptr(partial), ptr(out), _i64(n), _i32(splits), _i64(slab),
+                                  _i32(out.dtype == torch.bfloat16), _i32(bool(accumulate)),
+                                  stream()), "splitk_reduce")
+
+
+# ---- batch norm / pooling / loss (csrc/kernels/nn_kernels.hip) -------------------------------
+def bn_stats_partial(y2d, partial, M, C, rows_per_tile):
+    check(lib().ddl_bn_stats_partial(ptr(y2d), ptr(partial), _i64(M), _i32(C), _i32(rows_per_tile),
+                                     stream()), "bn_stats_partial")
+
+
+def bn_fwd_finalize(partial, T, C, M, rows_per_tile, gamma, beta, rmean, rvar, momentum, eps,
+                    mean, invstd, scale, shift):
+    check(lib().ddl_bn_fwd_finalize(ptr(partial), _i32(T), _i32(C), _i64(M), _i32(rows_per_tile),
+                                    ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), _f32(momentum),
+                                    _f32(eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                    stream()), "bn_fwd_finalize")
+
+
+def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):
+    check(lib().ddl_bn_eval_coeffs(ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), _f32(eps),
+                                   _i32(gamma.numel()), ptr(scale), ptr(shift), stream()),
+          "bn_eval_coeffs")
+
+
+def bn_apply_fwd(y, scale, shift, res, z, M, C, relu):
+    check(lib().ddl_bn_apply_fwd(ptr(y), ptr(scale), ptr(shift), ptr(res), ptr(z), _i64(M), _i32(C),
+                                 _i32(bool(relu)), stream()), "bn_apply_fwd")
+
+
+def bn_bwd_blocks(M):
+    return int(lib().ddl_bn_bwd_blocks(_i64(M)))
+
+
+def bn_bwd_reduce(dz, y, z, partial, M, C, relu, G):
+    check(lib().ddl_bn_bwd_reduce(ptr(dz), ptr(y), ptr(z), ptr(partial), _i64(M), _i32(C),
+                                  _i32(bool(relu)), _i32(G), stream()), "bn_bwd_reduce")
+
+
+def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef):
+    check(lib().ddl_bn_bwd_finalize(ptr(partial), _i32(G), _i32(C), _i64(M), ptr(gamma), ptr(mean),
+                                    ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(coef), stream()),
+          "bn_bwd_finalize")
+
+
+def bn_bwd_apply(dz, y, z, coef, dy, gout, M, C, relu):
+    check(lib().ddl_bn_bwd_apply(ptr(dz), ptr(y), ptr(z), ptr(coef), ptr(dy), ptr(gout), _i64(M),
+                                 _i32(C), _i32(bool(relu)), stream()), "bn_bwd_apply")
+
+
+def maxpool_fwd(x, out, idx, B, H, W, C):
+    check(lib().ddl_maxpool3x3s2_fwd(ptr(x), ptr(out), ptr(idx), _i32(B), _i32(H), _i32(W), _i32(C),
+                                     stream()), "maxpool_fwd")
+
+
+def maxpool_bwd(dy, idx, dx, B, H, W, C):
+    check(lib().ddl_maxpool3x3s2_bwd(ptr(dy), ptr(idx), ptr(dx), _i32(B), _i32(H), _i32(W), _i32(C),
+                                     stream()), "maxpool_bwd")
+
+
+def avgpool_fwd(x, out, B, HW, C):
+    check(lib().ddl_avgpool_fwd(ptr(x), ptr(out), _i32(B), _i32(HW), _i32(C), stream()), "avgpool_fwd")
+
+
+def avgpool_bwd(dy, dx, B, HW, C):
+    check(lib().ddl_avgpool_bwd(ptr(dy), ptr(dx), _i32(B), _i32(HW), _i32(C), stream()), "avgpool_bwd")
+
+
+def softmax_xent(logits, labels, loss_rows, dlogits, B, N, ldl, ldd, grad_scale):
+    check(lib().ddl_softmax_xent(ptr(logits), ptr(labels), ptr(loss_rows), ptr(dlogits), _i32(B),
+                                 _i32(N), _i32(ldl), _i32(ldd), _f32(grad_scale), stream()),
+          "softmax_xent")
+
+
+def bias_add_(y, bias, M, N):
+    check(lib().ddl_bias_add(ptr(y), ptr(bias), _i64(M), _i32(N), stream()), "bias_add")
+
+
+def colsum(a, out, M, N, ld):
+    check(lib().ddl_colsum(ptr(a), ptr(out), _i32(M), _i32(N), _i32(ld), stream()), "colsum")
+
+
+def weight_flip_transpose(base_src_addr, base_dst_addr, table, nentries, total_blocks):
+    check(lib().ddl_weight_flip_transpose(ctypes.c_void_p(base_src_addr), ctypes.c_void_p(base_dst_addr),
+                                          ptr(table), _i32(nentries), _i32(total_blocks), stream()),
+          "weight_flip_transpose")
+
+
+def stem_pack(x, out):
+    B, C, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    check(lib().ddl_stem_pack(ptr(x), ptr(out), _i32(B), _i32(H), _i32(W), _i32(C), _i64(sb), _i64(sh),
+                              _i64(sw), _i64(sc), stream()), "stem_pack")

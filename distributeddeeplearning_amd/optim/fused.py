@@ -90,6 +90,13 @@ class _ArenaOptimizer(Optimizer):
     def zero_grad(self, set_to_none=False):
         self.arena.zero_()
 
+    @staticmethod
+    def _notify_weights_changed(hip):
+        if hip:  # parameters were rewritten through raw pointers: drop derived weight copies
+            from ..ops import hip_ops
+
+            hip_ops.weights_changed()
+
     # -- checkpoint surface ----------------------------------------------------------------
     def state_dict(self):
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
@@ -204,6 +211,7 @@ class FusedSGD(_ArenaOptimizer):
             w.add_(g.add(v, alpha=mu) if nesterov else v, alpha=-lr)
             self._publish(dt, a, b)
         self._step += 1
+        self._notify_weights_changed(hip)
         return loss
 
 
@@ -288,4 +296,5 @@ class FusedLARS(_ArenaOptimizer):
                 w[sl].sub_(v[sl])
             self._publish(dt, a, b)
         self._step += 1
+        self._notify_weights_changed(hip)
         return loss

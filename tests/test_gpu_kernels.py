@@ -1,0 +1,294 @@
+"""GPU numerics tests: every HIP kernel against a plain PyTorch fp32 reference of the same op.
+
+Run on an MI355X with ``python -m pytest tests -m gpu``.  Strategy follows SURVEY §4: all
+ResNet-50 conv shape classes x forward / backward-data / backward-weights, BatchNorm
+forward/backward, pooling, dense head, loss, the fused optimizers and the synthetic generator.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+BF = torch.bfloat16
+CL = torch.channels_last
+
+
+def _hip():
+    from distributeddeeplearning_amd.ops import hip_ops, kernels
+
+    kernels.require()
+    return hip_ops
+
+
+def relerr(a, ref):
+    a, ref = a.float(), ref.float()
+    return float((a - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
+
+
+def rms_relerr(a, ref):
+    a, ref = a.float(), ref.float()
+    return float((a - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
+
+
+def rand_nhwc(B, C, H, W, scale=1.0, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = (torch.randn((B, C, H, W), generator=g, device=DEV) * scale).to(BF)
+    return x.contiguous(memory_format=CL)
+
+
+CONV_CASES = [
+    # (B, Cin, H, W, Cout, k, stride, pad)   -- shape classes of SURVEY §2.7
+    (4, 64, 56, 56, 64, 1, 1, 0),     # a1
+    (4, 256, 56, 56, 64, 1, 1, 0),    # a2
+    (4, 64, 56, 56, 64, 3, 1, 1),     # a3
+    (4, 64, 56, 56, 256, 1, 1, 0),    # a4
+    (3, 128, 56, 56, 128, 3, 2, 1),   # b2  (odd batch -> ragged M tile)
+    (4, 256, 56, 56, 512, 1, 2, 0),   # b6  1x1 stride 2
+    (5, 256, 14, 14, 256, 3, 1, 1),   # c4
+    (4, 1024, 14, 14, 256, 1, 1, 0),  # c3
+    (6, 512, 7, 7, 512, 3, 1, 1),     # d4
+    (6, 512, 7, 7, 2048, 1, 1, 0),    # d5
+    (2, 512, 14, 14, 512, 3, 2, 1),   # d2
+    (2, 32, 9, 11, 96, 3, 1, 1),      # BK=32 path, odd sizes, Cout not a tile multiple
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case):
+    hip = _hip()
+    B, Cin, H, W, Cout, k, stride, pad = case
+    x = rand_nhwc(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = (torch.randn((Cout, Cin, k, k), device=DEV) / math.sqrt(Cin * k * k)).to(BF)
+    w = w.contiguous(memory_format=CL).requires_grad_(True)
+    y, stats = hip.conv2d_stats(x, w, stride, pad, True)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    assert y.shape == yr.shape
+    assert relerr(y, yr) < 1.5e-2 and rms_relerr(y, yr) < 4e-3
+    # fused statistics = column sums of the bf16 output
+    y2 = y.detach().float().permute(0, 2, 3, 1).reshape(-1, Cout)
+    s1 = stats[:, 0, :].sum(0)
+    s2 = stats[:, 1, :].sum(0)
+    assert torch.allclose(s1, y2.sum(0), rtol=1e-3, atol=1e-2 * float(y2.abs().max()))
+    assert torch.allclose(s2, (y2 * y2).sum(0), rtol=1e-3, atol=1e-3)
+    g = rand_nhwc(*y.shape, seed=2)
+    y.backward(g)
+    yr.backward(g.float())
+    assert relerr(x.grad, xr.grad) < 1.5e-2 and rms_relerr(x.grad, xr.grad) < 4e-3
+    assert relerr(w.grad, wr.grad) < 1.5e-2 and rms_relerr(w.grad, wr.grad) < 4e-3
+
+
+def test_stem_conv():
+    hip = _hip()
+    B, H, W = 3, 64, 96
+    x = torch.rand((B, 3, H, W), device=DEV).to(BF).contiguous(memory_format=CL)
+    w = (torch.randn((64, 3, 7, 7), device=DEV) / math.sqrt(147)).to(BF)
+    w = w.contiguous(memory_format=CL).requires_grad_(True)
+    y, stats = hip.conv2d_stats(x, w, 2, 3, True)
+    wr = w.detach().float().requires_grad_(True)
+    yr = F.conv2d(x.float(), wr, None, 2, 3)
+    assert y.shape == yr.shape
+    assert relerr(y, yr) < 1.5e-2
+    g = rand_nhwc(*y.shape, seed=3)
+    y.backward(g)
+    yr.backward(g.float())
+    assert relerr(w.grad, wr.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("shape", [(4, 64, 28, 28), (3, 256, 7, 9), (2, 2048, 7, 7)])
+def test_batchnorm_act(shape, relu, res):
+    hip = _hip()
+    B, C, H, W = shape
+    y = (rand_nhwc(B, C, H, W, scale=2.0, seed=4).float() + 0.5).to(BF).contiguous(memory_format=CL)
+    y.requires_grad_(True)
+    gamma = (torch.rand(C, device=DEV) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, device=DEV) * 0.1).requires_grad_(True)
+    r = rand_nhwc(B, C, H, W, seed=5).requires_grad_(True) if res else None
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    z = hip.batchnorm_act(y, gamma, beta, rm, rv, True, 0.1, 1e-5, relu, r)
+    yr = y.detach().float().requires_grad_(True)
+    gr, br = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    rr = r.detach().float().requires_grad_(True) if res else None
+    rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    zr = F.batch_norm(yr, rm2, rv2, gr, br, True, 0.1, 1e-5)
+    if res:
+        zr = zr + rr
+    if relu:
+        zr = F.relu(zr)
+    assert relerr(z, zr) < 1.5e-2
+    assert torch.allclose(rm, rm2, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(rv, rv2, rtol=1e-3, atol=1e-4)
+    g = rand_nhwc(B, C, H, W, seed=6)
+    # use the kernel's own activation pattern for the reference too (bf16 rounding can flip
+    # elements that sit exactly at the ReLU threshold)
+    z.backward(g)
+    zr.backward(g.float())
+    assert rms_relerr(y.grad, yr.grad) < 1e-2
+    assert relerr(gamma.grad, gr.grad) < 1e-2
+    assert relerr(beta.grad, br.grad) < 1e-2
+    if res:
+        assert rms_relerr(r.grad, rr.grad) < 1e-2
+
+
+def test_batchnorm_eval():
+    hip = _hip()
+    B, C, H, W = 2, 128, 5, 5
+    y = rand_nhwc(B, C, H, W, seed=7)
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    rm, rv = torch.randn(C, device=DEV), torch.rand(C, device=DEV) + 0.5
+    z = hip.batchnorm_act(y, gamma, beta, rm, rv, False, 0.1, 1e-5, True, None)
+    zr = F.relu(F.batch_norm(y.float(), rm, rv, gamma, beta, False, 0.1, 1e-5))
+    assert relerr(z, zr) < 1.5e-2
+
+
+def test_maxpool():
+    hip = _hip()
+    for (B, C, H, W) in [(2, 64, 112, 112), (3, 64, 17, 23)]:
+        x = F.relu(rand_nhwc(B, C, H, W, seed=8)).contiguous(memory_format=CL).requires_grad_(True)
+        out = hip.maxpool3x3s2(x)
+        xr = x.detach().float().requires_grad_(True)
+        outr = F.max_pool2d(xr, 3, 2, 1)
+        assert torch.equal(out.float(), outr)
+        g = rand_nhwc(*out.shape, seed=9)
+        out.backward(g)
+        outr.backward(g.float())
+        assert relerr(x.grad, xr.grad) < 1e-2
+
+
+def test_global_avgpool():
+    hip = _hip()
+    x = rand_nhwc(5, 2048, 7, 7, seed=10).requires_grad_(True)
+    out = hip.global_avgpool(x)
+    xr = x.detach().float().requires_grad_(True)
+    outr = xr.mean(dim=(2, 3))
+    assert relerr(out, outr) < 1e-2
+    g = torch.randn_like(outr).to(BF)
+    out.backward(g)
+    outr.backward(g.float())
+    assert relerr(x.grad, xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("B,Cin,N", [(32, 2048, 1000), (7, 512, 1000), (256, 2048, 1024)])
+def test_linear(B, Cin, N):
+    hip = _hip()
+    x = (torch.randn(B, Cin, device=DEV)).to(BF).requires_grad_(True)
+    w = (torch.randn(N, Cin, device=DEV) * 0.02).to(BF).requires_grad_(True)
+    b = torch.randn(N, device=DEV).requires_grad_(True)
+    y = hip.linear(x, w, b)
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    assert relerr(y, yr) < 1.5e-2
+    g = torch.randn_like(yr).to(BF)
+    y.backward(g)
+    yr.backward(g.float())
+    assert relerr(x.grad, xr.grad) < 1.5e-2
+    assert relerr(w.grad, wr.grad) < 1.5e-2
+    assert relerr(b.grad, br.grad) < 1e-2
+
+
+def test_softmax_cross_entropy():
+    hip = _hip()
+    B, N = 37, 1000
+    logits = (torch.randn(B, N, device=DEV) * 3).to(BF).requires_grad_(True)
+    target = torch.randint(0, N, (B,), device=DEV)
+    loss = hip.softmax_cross_entropy(logits, target)
+    lr = logits.detach().float().requires_grad_(True)
+    lossr = F.cross_entropy(lr, target)
+    assert abs(float(loss) - float(lossr)) < 2e-3 * max(1.0, abs(float(lossr)))
+    loss.backward()
+    lossr.backward()
+    assert relerr(logits.grad, lr.grad) < 1e-2
+
+
+def test_weight_cache_tracks_updates():
+    hip = _hip()
+    hip.reset_caches()
+    x = rand_nhwc(2, 64, 8, 8, seed=11).requires_grad_(True)
+    w = (torch.randn((64, 64, 3, 3), device=DEV) * 0.05).to(BF).contiguous(memory_format=CL)
+    w.requires_grad_(True)
+    for it in range(2):
+        x.grad = None
+        y = hip.conv2d(x, w, 1, 1)
+        y.backward(torch.ones_like(y))
+        xr = x.detach().float().requires_grad_(True)
+        F.conv2d(xr, w.detach().float(), None, 1, 1).backward(torch.ones_like(y).float())
+        assert relerr(x.grad, xr.grad) < 1.5e-2
+        with torch.no_grad():
+            w.mul_(-0.5)  # in-place update must invalidate the transposed copy
+
+
+def test_resnet50_matches_aten_path():
+    """End-to-end: tiny-batch ResNet-50 forward/backward on the HIP kernels against the same
+    model driven through ATen ops."""
+    from distributeddeeplearning_amd.models import resnet50
+    from distributeddeeplearning_amd.ops import functional as ops
+
+    _hip().reset_caches()
+    torch.manual_seed(0)
+    model = resnet50(num_classes=1000).to_compute(torch.device(DEV), BF).train()
+    x = torch.rand((4, 3, 64, 64), device=DEV).to(BF).contiguous(memory_format=CL)
+    t = torch.randint(0, 1000, (4,), device=DEV)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def run(backend):
+        ops.set_backend(backend)
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        logits = model(x)
+        loss = ops.softmax_cross_entropy(logits, t)
+        loss.backward()
+        return logits.detach().float(), float(loss), {n: p.grad.detach().float().clone()
+                                                      for n, p in model.named_parameters()}
+
+    try:
+        lh, loss_h, gh = run("auto")
+        la, loss_a, ga = run("aten")
+    finally:
+        ops.set_backend("auto")
+    assert abs(loss_h - loss_a) < 5e-2
+    assert rms_relerr(lh, la) < 5e-2
+    for name in ("fc.weight", "layer4.2.conv3.weight", "layer1.0.conv1.weight", "conv1.weight"):
+        assert rms_relerr(gh[name], ga[name]) < 0.15, name
+
+
+def test_fused_sgd_matches_torch():
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(64, 32).to(DEV)
+    ref = torch.nn.Linear(64, 32).to(DEV)
+    ref.load_state_dict(lin.state_dict())
+    opt = FusedSGD(lin.named_parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3,
+                   weight_decay_filter=lambda n, p: True)
+    opt_r = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+    for _ in range(3):
+        x = torch.randn(16, 64, device=DEV)
+        opt.zero_grad()
+        opt_r.zero_grad()
+        lin(x).pow(2).mean().backward()
+        ref(x).pow(2).mean().backward()
+        opt.step()
+        opt_r.step()
+    assert torch.allclose(lin.weight, ref.weight, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(lin.bias, ref.bias, rtol=1e-5, atol=1e-6)
+
+
+def test_philox_statistics():
+    from distributeddeeplearning_amd.ops import kernels
+
+    kernels.require()
+    t = torch.empty(1 << 20, dtype=BF, device=DEV)
+    kernels.philox_uniform_(t, 42)
+    f = t.float()
+    assert 0.0 <= float(f.min()) and float(f.max()) < 1.0
+    assert abs(float(f.mean()) - 0.5) < 5e-3
+    assert abs(float(f.var()) - 1.0 / 12) < 5e-3
+    lab = torch.empty(1 << 16, dtype=torch.int64, device=DEV)
+    kernels.philox_labels_(lab, 1000, 7)
+    assert int(lab.min()) >= 0 and int(lab.max()) < 1000
