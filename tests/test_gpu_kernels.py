@@ -223,38 +223,77 @@ def test_weight_cache_tracks_updates():
             w.mul_(-0.5)  # in-place update must invalidate the transposed copy
 
 
-def test_resnet50_matches_aten_path():
-    """End-to-end: tiny-batch ResNet-50 forward/backward on the HIP kernels against the same
-    model driven through ATen ops."""
-    from distributeddeeplearning_amd.models import resnet50
+def test_bottleneck_block_matches_fp32_reference():
+    """One projection bottleneck (4 convs, 4 BNs, residual) forward + backward on the HIP kernels
+    against the same block evaluated by ATen in fp32; the error budget is the error of the
+    stock bf16 ATen/MIOpen path against that same fp32 reference (x2).  (Whole-network
+    comparisons are not meaningful: a random-init ResNet-50 in training mode amplifies bf16
+    rounding noise by ~1.3x per block and even two ATen runs of it disagree by >50 % in the
+    early-layer gradients — measured with scripts/debug_e2e.py.)"""
+    from distributeddeeplearning_amd.models.resnet import Bottleneck
     from distributeddeeplearning_amd.ops import functional as ops
 
     _hip().reset_caches()
     torch.manual_seed(0)
-    model = resnet50(num_classes=1000).to_compute(torch.device(DEV), BF).train()
-    x = torch.rand((4, 3, 64, 64), device=DEV).to(BF).contiguous(memory_format=CL)
-    t = torch.randint(0, 1000, (4,), device=DEV)
-    state = {k: v.clone() for k, v in model.state_dict().items()}
 
-    def run(backend):
+    def make(dtype):
+        torch.manual_seed(0)
+        m = Bottleneck(256, 128, 2, True, False).to(DEV).train()
+        for mod in m.modules():
+            if hasattr(mod, "kernel"):
+                wq = mod.weight.data.to(BF)  # every variant sees the same bf16-rounded weights
+                mod.weight.data = wq.to(dtype).contiguous(memory_format=CL)
+        return m
+
+    x = rand_nhwc(8, 256, 28, 28, seed=12)
+    g = rand_nhwc(8, 512, 14, 14, seed=13)
+
+    def run(m, backend, dtype):
         ops.set_backend(backend)
-        model.load_state_dict(state)
-        model.zero_grad(set_to_none=True)
-        logits = model(x)
-        loss = ops.softmax_cross_entropy(logits, t)
-        loss.backward()
-        return logits.detach().float(), float(loss), {n: p.grad.detach().float().clone()
-                                                      for n, p in model.named_parameters()}
+        try:
+            xi = x.detach().to(dtype).requires_grad_(True)
+            out = m(xi)
+            out.backward(g.to(dtype))
+        finally:
+            ops.set_backend("auto")
+        grads = {n: p.grad.detach().float() for n, p in m.named_parameters()}
+        return out.detach().float(), xi.grad.detach().float(), grads
 
-    try:
-        lh, loss_h, gh = run("auto")
-        la, loss_a, ga = run("aten")
-    finally:
-        ops.set_backend("auto")
-    assert abs(loss_h - loss_a) < 5e-2
-    assert rms_relerr(lh, la) < 5e-2
-    for name in ("fc.weight", "layer4.2.conv3.weight", "layer1.0.conv1.weight", "conv1.weight"):
-        assert rms_relerr(gh[name], ga[name]) < 0.15, name
+    o_ref, dx_ref, g_ref = run(make(torch.float32), "aten", torch.float32)
+    o_at, dx_at, g_at = run(make(BF), "aten", BF)
+    o_hip, dx_hip, g_hip = run(make(BF), "auto", BF)
+
+    def ok(h, a, r, what):
+        eh, ea = rms_relerr(h, r), rms_relerr(a, r)
+        assert eh < max(2.0 * ea, 2e-2), "%s: hip %.4f vs stock bf16 %.4f" % (what, eh, ea)
+
+    ok(o_hip, o_at, o_ref, "output")
+    ok(dx_hip, dx_at, dx_ref, "dx")
+    for n in g_ref:
+        ok(g_hip[n], g_at[n], g_ref[n], n)
+
+
+def test_resnet50_trains_on_hip_kernels():
+    """End-to-end: ResNet-50 on the HIP path memorises one small batch (loss must fall)."""
+    from distributeddeeplearning_amd.models import resnet50
+    from distributeddeeplearning_amd.ops import functional as ops
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    _hip().reset_caches()
+    torch.manual_seed(0)
+    model = resnet50(num_classes=1000, zero_init_residual=True).to_compute(torch.device(DEV), BF).train()
+    opt = FusedSGD(model.named_parameters(), lr=0.05, momentum=0.9)
+    x = torch.rand((16, 3, 64, 64), device=DEV).to(BF).contiguous(memory_format=CL)
+    t = torch.randint(0, 1000, (16,), device=DEV)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = ops.softmax_cross_entropy(model(x), t)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(math.isfinite(l) for l in losses), losses
+    assert losses[-1] < 0.5 * losses[0], losses
 
 
 def test_fused_sgd_matches_torch():
