@@ -60,9 +60,23 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--pure-bf16", action="store_true",
                     help="bf16 parameters instead of fp32 parameters under autocast")
+    ap.add_argument("--autotune", action="store_true",
+                    help="cudnn.benchmark=True as in the reference (:319); MIOpen's exhaustive "
+                         "find can take minutes on a fresh box")
     args = ap.parse_args()
     dev = torch.device("cuda")
-    torch.backends.cudnn.benchmark = True  # the reference sets cudnn.benchmark=True (:319)
+    torch.backends.cudnn.benchmark = bool(args.autotune)
+    import threading
+
+    stop = threading.Event()
+
+    def heartbeat():  # MIOpen find mode is silent for minutes; keep the log moving
+        n = 0
+        while not stop.wait(30):
+            n += 30
+            print("[stock_pytorch] still running (%d s)" % n, flush=True)
+
+    threading.Thread(target=heartbeat, daemon=True).start()
     torch.manual_seed(42)
     model = ResNet50().to(dev).to(memory_format=torch.channels_last)
     if args.pure_bf16:
@@ -93,7 +107,8 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"metric": "stock PyTorch-ROCm ResNet-50 images/sec", "mode":
+    stop.set()
+    print(json.dumps({"metric": "stock PyTorch-ROCm ResNet-50 images/sec", "autotune": bool(args.autotune), "mode":
                       "pure_bf16" if args.pure_bf16 else "autocast_bf16",
                       "value": round(args.batch * args.steps / el, 2), "batch": args.batch,
                       "ms_per_step": round(el / args.steps * 1e3, 3),

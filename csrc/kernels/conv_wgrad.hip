@@ -195,29 +195,46 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
         }
 }
 
-// out[i] = scale * sum_s partial[s][i]  (fixed order), bf16 or fp32 output, optional accumulate
-template <typename OutT, bool ACCUM>
+// out[i] = sum_s partial[s][i] (fixed order => deterministic), bf16 or fp32 output.
+// Block = (256 / SL) float4 columns x SL split lanes, so that tall-and-narrow reductions (a 64x64
+// 1x1 conv weight summed over 512 slabs) still spread over many CUs with short dependent chains.
+template <typename OutT, bool ACCUM, int SL>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ partial, OutT* __restrict__ out,
                                                            long long n, int splits, long long slab) {
-    long long n4 = n >> 2;
-    long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4 s = *reinterpret_cast<const f32x4*>(partial + (i << 2));
-        for (int k = 1; k < splits; ++k) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long long)k * slab + (i << 2));
-            s += v;
+    constexpr int COLS = 256 / SL;
+    __shared__ f32x4 red[SL > 1 ? 256 : 1];
+    const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+    const long long n4 = n >> 2;
+    const long long i = (long long)blockIdx.x * COLS + col;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        int k = sl;
+        for (; k + 3 * SL < splits; k += 4 * SL) {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(partial + (long long)k * slab + (i << 2));
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(partial + (long long)(k + SL) * slab + (i << 2));
+            f32x4 v2 = *reinterpret_cast<const f32x4*>(partial + (long long)(k + 2 * SL) * slab + (i << 2));
+            f32x4 v3 = *reinterpret_cast<const f32x4*>(partial + (long long)(k + 3 * SL) * slab + (i << 2));
+            s += (v0 + v1) + (v2 + v3);
         }
-        if constexpr (sizeof(OutT) == 4) {
-            f32x4* o = reinterpret_cast<f32x4*>(out + (i << 2));
-            if (ACCUM) s += *o;
-            *o = s;
-        } else {
-            bf16x4* o = reinterpret_cast<bf16x4*>(out + (i << 2));
-            if (ACCUM) { bf16x4 old = *o; for (int e = 0; e < 4; ++e) s[e] += bf2f(old[e]); }
-            bf16x4 v;
-            for (int e = 0; e < 4; ++e) v[e] = f2bf(s[e]);
-            *o = v;
-        }
+        for (; k < splits; k += SL) s += *reinterpret_cast<const f32x4*>(partial + (long long)k * slab + (i << 2));
+    }
+    if (SL > 1) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sl != 0) return;
+        for (int l = 1; l < SL; ++l) s += red[l * COLS + col];
+    }
+    if (i >= n4) return;
+    if constexpr (sizeof(OutT) == 4) {
+        f32x4* o = reinterpret_cast<f32x4*>(out + (i << 2));
+        if (ACCUM) s += *o;
+        *o = s;
+    } else {
+        bf16x4* o = reinterpret_cast<bf16x4*>(out + (i << 2));
+        if (ACCUM) { bf16x4 old = *o; for (int e = 0; e < 4; ++e) s[e] += bf2f(old[e]); }
+        bf16x4 v;
+        for (int e = 0; e < 4; ++e) v[e] = f2bf(s[e]);
+        *o = v;
     }
 }
 
@@ -241,7 +258,7 @@ extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S) {
     long long max_by_m = (M + 255) / 256;                  // at least 256 reduction rows per split
     if (want > max_by_m) want = max_by_m;
     if (want < 1) want = 1;
-    if (want > 1024) want = 1024;
+    if (want > 512) want = 512;
     return (int)want;
 }
 
@@ -289,10 +306,14 @@ extern "C" int ddl_splitk_reduce(const void* partial, void* out, long long n, in
     if (!partial || !out || n <= 0 || splits <= 0 || (n & 3) || slab < n || (slab & 3)) return DDL_EINVAL;
     if (!ddl_aligned16(partial) || (reinterpret_cast<uintptr_t>(out) & 7)) return DDL_EALIGN;
     if (!out_is_bf16 && !ddl_aligned16(out)) return DDL_EALIGN;
-    dim3 grid(ddl_stream_grid(n / 4, 256)), block(256);
-#define RL(T, A) hipLaunchKernelGGL((splitk_reduce_kernel<T, A>), grid, block, 0, stream, (const float*)partial, (T*)out, n, splits, slab)
+    const long long n4 = n / 4;
+    const int sl = splits >= 64 ? 16 : (splits >= 8 ? 4 : 1);
+    dim3 grid((unsigned)((n4 + 256 / sl - 1) / (256 / sl))), block(256);
+#define RL3(T, A, S) hipLaunchKernelGGL((splitk_reduce_kernel<T, A, S>), grid, block, 0, stream, (const float*)partial, (T*)out, n, splits, slab)
+#define RL(T, A) do { if (sl == 16) RL3(T, A, 16); else if (sl == 4) RL3(T, A, 4); else RL3(T, A, 1); } while (0)
     if (out_is_bf16) { if (accumulate) RL(bf16_t, true); else RL(bf16_t, false); }
     else { if (accumulate) RL(float, true); else RL(float, false); }
+#undef RL3
 #undef RL
     return ddl_launch_status();
 }

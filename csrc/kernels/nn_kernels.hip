@@ -48,56 +48,73 @@ __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const bf16_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6b: combine tile partials (sum, sum of squares over rows_per_tile rows each) into mean / invstd
-// with Chan's parallel-variance update (cancellation stays inside a tile), update the running
-// statistics (unbiased variance, like torch) and emit the fused scale/shift of K7.
-// Block = 64 channels x 16 tile lanes.
+// K6b: combine the per-tile partials [T][2][C] (sum, sum of squares of `rows_per_tile` rows each)
+// into mean / invstd.  Two small launches so that the 3-13 MB partial table of the 56x56 layers
+// is read by many CUs: stage 1 folds T/P tiles per block in fp64 (no cancellation across tiles),
+// stage 2 (one thread per channel) folds the P slices, updates the running statistics (unbiased
+// variance, like torch) and emits the fused scale/shift of K7.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) bn_fwd_finalize_kernel(const float* __restrict__ partial, int T, int C, long long M,
-                                                              int rows_per_tile, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ rmean,
-                                                              float* __restrict__ rvar, float momentum, float eps,
-                                                              float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                              float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ float sn[16][64], sm[16][64], sq[16][64];
+__global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restrict__ partial, int T, int C, int P,
+                                                           double* __restrict__ folded /*[P][2][C]*/) {
+    __shared__ double r1[4][64], r2[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
+    const int per = (T + P - 1) / P;
+    const int t0 = blockIdx.y * per;
+    int t1 = t0 + per;
+    if (t1 > T) t1 = T;
+    double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int t = ty; t < T; t += 16) {
-            long long rows = M - (long long)t * rows_per_tile;
-            if (rows > rows_per_tile) rows = rows_per_tile;
-            float nt = (float)rows;
-            float a = partial[((long long)t * 2) * C + c], b = partial[((long long)t * 2 + 1) * C + c];
-            float mt = a / nt, m2t = fmaxf(b - a * mt, 0.f);
-            float tot = n + nt, d = mt - mean;
-            mean += d * (nt / tot);
-            m2 += m2t + d * d * (n * nt / tot);
-            n = tot;
+        int t = t0 + ty;
+        for (; t + 12 < t1; t += 16) {
+            float a0 = partial[((long long)t * 2) * C + c], b0 = partial[((long long)t * 2 + 1) * C + c];
+            float a1 = partial[((long long)(t + 4) * 2) * C + c], b1 = partial[((long long)(t + 4) * 2 + 1) * C + c];
+            float a2 = partial[((long long)(t + 8) * 2) * C + c], b2 = partial[((long long)(t + 8) * 2 + 1) * C + c];
+            float a3 = partial[((long long)(t + 12) * 2) * C + c], b3 = partial[((long long)(t + 12) * 2 + 1) * C + c];
+            s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; t < t1; t += 4) {
+            s1 += (double)partial[((long long)t * 2) * C + c];
+            s2 += (double)partial[((long long)t * 2 + 1) * C + c];
         }
     }
-    sn[ty][tx] = n; sm[ty][tx] = mean; sq[ty][tx] = m2;
+    r1[ty][tx] = s1; r2[ty][tx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
-        for (int l = 1; l < 16; ++l) {
-            float nt = sn[l][tx];
-            if (nt > 0.f) {
-                float tot = n + nt, d = sm[l][tx] - mean;
-                mean += d * (nt / tot);
-                m2 += sq[l][tx] + d * d * (n * nt / tot);
-                n = tot;
-            }
-        }
-        float var = m2 / n;
-        float inv = rsqrtf(var + eps);
-        mean_out[c] = mean; invstd_out[c] = inv;
-        float g = gamma[c] * inv;
-        scale[c] = g; shift[c] = beta[c] - mean * g;
-        if (rmean) {
-            float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
-        }
+        s1 = (r1[0][tx] + r1[1][tx]) + (r1[2][tx] + r1[3][tx]);
+        s2 = (r2[0][tx] + r2[1][tx]) + (r2[2][tx] + r2[3][tx]);
+        folded[((long long)blockIdx.y * 2) * C + c] = s1;
+        folded[((long long)blockIdx.y * 2 + 1) * C + c] = s2;
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const double* __restrict__ folded, int P, int C, long long M,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ rmean, float* __restrict__ rvar,
+                                                             float momentum, float eps, float* __restrict__ mean_out,
+                                                             float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                             float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < P; ++p) {
+        s1 += folded[((long long)p * 2) * C + c];
+        s2 += folded[((long long)p * 2 + 1) * C + c];
+    }
+    const double n = (double)M;
+    const double mean = s1 / n;
+    double m2 = s2 - s1 * mean;
+    if (m2 < 0.0) m2 = 0.0;
+    const float var = (float)(m2 / n);
+    const float inv = rsqrtf(var + eps);
+    mean_out[c] = (float)mean; invstd_out[c] = inv;
+    const float g = gamma[c] * inv;
+    scale[c] = g; shift[c] = beta[c] - (float)mean * g;
+    if (rmean) {
+        const float unbiased = M > 1 ? (float)(m2 / (n - 1.0)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
     }
 }
 
@@ -504,13 +521,25 @@ extern "C" int ddl_bn_stats_partial(const void* y, void* partial, long long M, i
     return ddl_launch_status();
 }
 
+// workspace (doubles) needed by ddl_bn_fwd_finalize for T tiles of C channels
+extern "C" long long ddl_bn_fold_slices(int T) {
+    int P = T / 32;
+    if (P < 1) P = 1;
+    if (P > 64) P = 64;
+    return P;
+}
+
 extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long M, int rows_per_tile, const void* gamma,
                                    const void* beta, void* rmean, void* rvar, float momentum, float eps, void* mean,
-                                   void* invstd, void* scale, void* shift, hipStream_t stream) {
-    CHK(partial && gamma && beta && mean && invstd && scale && shift && T > 0 && C > 0 && M > 0, DDL_EINVAL);
+                                   void* invstd, void* scale, void* shift, void* workspace, hipStream_t stream) {
+    CHK(partial && gamma && beta && mean && invstd && scale && shift && workspace && T > 0 && C > 0 && M > 0, DDL_EINVAL);
     CHK((long long)T * rows_per_tile >= M && (long long)(T - 1) * rows_per_tile < M, DDL_EINVAL);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, T, C, M,
-                       rows_per_tile, (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
+    CHK((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, DDL_EALIGN);
+    const int P = (int)ddl_bn_fold_slices(T);
+    hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
+                       (double*)workspace);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)workspace, P, C, M,
+                       (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
                        (float*)mean, (float*)invstd, (float*)scale, (float*)shift);
     return ddl_launch_status();
 }

@@ -196,10 +196,12 @@ def bn_stats_partial(y2d, partial, M, C, rows_per_tile):
 
 def bn_fwd_finalize(partial, T, C, M, rows_per_tile, gamma, beta, rmean, rvar, momentum, eps,
                     mean, invstd, scale, shift):
+    P = int(lib().ddl_bn_fold_slices(_i32(T)))
+    work = torch.empty((P, 2, C), dtype=torch.float64, device=partial.device)
     check(lib().ddl_bn_fwd_finalize(ptr(partial), _i32(T), _i32(C), _i64(M), _i32(rows_per_tile),
                                     ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), _f32(momentum),
                                     _f32(eps), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                    stream()), "bn_fwd_finalize")
+                                    ptr(work), stream()), "bn_fwd_finalize")
 
 
 def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):

@@ -1,0 +1,141 @@
+"""Worker body for the multi-process tests (launched by ``launch.run.launch`` with gloo)."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import distributeddeeplearning_amd.torch as hvd  # noqa: E402
+
+
+def emit(**kw):
+    print("RESULT " + json.dumps(kw, sort_keys=True), flush=True)
+
+
+def scenario_collectives():
+    hvd.init()
+    r, n = hvd.rank(), hvd.size()
+    t = torch.full((5,), float(r + 1))
+    avg = hvd.allreduce(t, name="t.avg")
+    s = hvd.allreduce(t, average=False, name="t.sum")
+    mx = hvd.allreduce(t, op=hvd.Max, name="t.max")
+    inplace = t.clone()
+    h = hvd.allreduce_async_(inplace, average=True, name="t.async")
+    assert isinstance(hvd.poll(h), bool)
+    hvd.synchronize(h)
+    b = torch.arange(4.0) * (r + 1)
+    hvd.broadcast_(b, root_rank=1, name="b")
+    g = hvd.allgather(torch.full((r + 1, 2), float(r)), name="g")  # ragged first dims
+    epoch = hvd.broadcast(7 if r == 0 else -1, 0, name="resume_from_epoch")
+    metrics = hvd.allreduce([float(r), 1.0])
+    objs = hvd.allgather_object({"rank": r})
+    emit(rank=r, size=n, local_rank=hvd.local_rank(), avg=avg.tolist(), sum=s.tolist(),
+         max=mx.tolist(), inplace=inplace.tolist(), bcast=b.tolist(), gather=g.flatten().tolist(),
+         epoch=epoch, metrics=metrics, objs=[o["rank"] for o in objs],
+         metric_average=hvd.metric_average(float(r)))
+    hvd.shutdown()
+
+
+def _tiny_model():
+    torch.manual_seed(1234)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.BatchNorm2d(4),
+                               torch.nn.ReLU(), torch.nn.Flatten(), torch.nn.Linear(4 * 8 * 8, 5))
+
+
+def scenario_optimizer_equivalence():
+    """2 ranks x batch 4 must equal 1 rank x batch 8."""
+    hvd.init()
+    r, n = hvd.rank(), hvd.size()
+    model = _tiny_model()
+    if r != 0:  # perturb: broadcast_parameters must equalise
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    hvd.broadcast_parameters(model.state_dict(), root_rank=0)
+    fused = os.environ.get("TEST_FUSED", "0") == "1"
+    if fused:
+        from distributeddeeplearning_amd.optim import FusedSGD
+
+        opt = FusedSGD(model.named_parameters(), lr=0.05, momentum=0.9)
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    opt = hvd.DistributedOptimizer(opt, named_parameters=model.named_parameters())
+    assert isinstance(opt, torch.optim.Optimizer)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(8, 3, 8, 8, generator=g)
+    y = torch.randint(0, 5, (8,), generator=g)
+    model.train()
+    # BatchNorm statistics are per-rank: freeze BN into eval so the comparison is exact
+    model[1].eval()
+    for _ in range(3):
+        xs, ys = x[r * 4:(r + 1) * 4], y[r * 4:(r + 1) * 4]
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(model(xs), ys).backward()
+        opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    emit(rank=r, params=flat.tolist(), buckets=opt.describe_buckets())
+    hvd.shutdown()
+
+
+def scenario_checkpoint_resume():
+    from distributeddeeplearning_amd.optim import FusedSGD
+    from distributeddeeplearning_amd.utils import checkpoint
+
+    hvd.init()
+    r = hvd.rank()
+    d = os.environ["TEST_CKPT_DIR"]
+    model = _tiny_model()
+    opt = hvd.DistributedOptimizer(FusedSGD(model.named_parameters(), lr=0.1, momentum=0.9),
+                                   named_parameters=model.named_parameters())
+    opt.zero_grad()
+    model(torch.randn(2, 3, 8, 8)).sum().backward()
+    opt.step()
+    path = checkpoint.save(d, 3, model, opt)  # only rank 0 writes
+    hvd.barrier()
+    wrote = path is not None
+    ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    ref = hvd.broadcast(ref, 0, name="ref")
+    # fresh, different model on every rank; resume must restore rank 0's checkpoint everywhere
+    torch.manual_seed(100 + r)
+    model2 = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.BatchNorm2d(4),
+                                 torch.nn.ReLU(), torch.nn.Flatten(), torch.nn.Linear(256, 5))
+    opt2 = hvd.DistributedOptimizer(FusedSGD(model2.named_parameters(), lr=0.1, momentum=0.9),
+                                    named_parameters=model2.named_parameters())
+    epoch = checkpoint.resume(d, model2, opt2)
+    got = torch.cat([p.detach().reshape(-1) for p in model2.parameters()])
+    mom = torch.cat([v.reshape(-1) for v in opt2.momentum_buf.values()])
+    emit(rank=r, wrote=wrote, epoch=epoch, max_diff=float((got - ref).abs().max()),
+         mom_norm=float(mom.norm()), files=sorted(os.listdir(d)))
+    hvd.shutdown()
+
+
+def scenario_fault():
+    """One rank dies mid-step (HVD_FAULT_INJECT); the job must end non-zero, not hang."""
+    hvd.init()
+    model = _tiny_model()
+    opt = hvd.DistributedOptimizer(torch.optim.SGD(model.parameters(), lr=0.1),
+                                   named_parameters=model.named_parameters())
+    for _ in range(5):
+        opt.zero_grad()
+        model(torch.randn(2, 3, 8, 8)).sum().backward()
+        opt.step()
+    emit(rank=hvd.rank(), survived=True)
+
+
+def scenario_mismatch():
+    os.environ["HVD_DEBUG"] = "1"
+    hvd.init()
+    t = torch.zeros(3 if hvd.rank() == 0 else 4)
+    try:
+        hvd.allreduce(t, name="bad")
+        emit(rank=hvd.rank(), raised=False)
+    except Exception as e:  # noqa: BLE001
+        emit(rank=hvd.rank(), raised=True, kind=type(e).__name__)
+    os._exit(0)
+
+
+if __name__ == "__main__":
+    globals()["scenario_" + sys.argv[1]]()

@@ -1,0 +1,170 @@
+"""Bucket planner, gradient arenas, fused optimizers, LR schedules, callbacks (CPU)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from distributeddeeplearning_amd import callbacks as cb
+from distributeddeeplearning_amd.models import resnet50
+from distributeddeeplearning_amd.optim import (FusedLARS, FusedSGD, LRSchedule, goyal_lr, poly_lr,
+                                               scaled_lr, staircase_multiplier)
+from distributeddeeplearning_amd.parallel.bucket import (BUCKET_ALIGN_BYTES, GradArena,
+                                                         SEG_ALIGN_BYTES, plan_arenas)
+from distributeddeeplearning_amd.parallel.compression import Compression
+
+
+def test_plan_reverse_order_caps_and_alignment():
+    entries = [("a", (1000,), torch.float32), ("b", (3000,), torch.float32),
+               ("c", (10,), torch.bfloat16), ("d", (5000,), torch.float32)]
+    plans = plan_arenas(entries, first_bucket_bytes=4096 * 4, bucket_cap_bytes=4096 * 4)
+    p32 = plans[torch.float32]
+    assert [s.name for s in p32.segments] == ["d", "b", "a"]  # reverse registration order
+    assert [len(b.segments) for b in p32.buckets] == [1, 2]   # d alone (over the cap), then b+a
+    for s in p32.segments:
+        assert (s.offset * 4) % SEG_ALIGN_BYTES == 0
+    for b in p32.buckets:
+        assert (b.end * 4) % BUCKET_ALIGN_BYTES == 0
+    assert torch.bfloat16 in plans and plans[torch.bfloat16].segments[0].name == "c"
+
+
+def test_resnet50_bucket_plan_is_small_and_ordered():
+    m = resnet50()
+    arena = GradArena(list(m.named_parameters()), 8 << 20, 32 << 20)
+    buckets = arena.all_buckets()
+    assert 3 <= len(buckets) <= 8  # 4-6 buckets for ResNet-50
+    first = buckets[0][1].segments[0].name
+    assert first.startswith("fc.")  # backward produces fc first
+    assert buckets[-1][1].segments[-1].name == "conv1.weight"
+    for _, p in m.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape
+    total = sum(b.numel for _, b in buckets)
+    assert total >= 25557032
+
+
+def test_grad_views_survive_backward_and_zero():
+    lin = torch.nn.Linear(8, 4)
+    arena = GradArena(list(lin.named_parameters()), 1 << 20, 1 << 20)
+    ptrs = {n: p.grad.data_ptr() for n, p in lin.named_parameters()}
+    lin(torch.randn(3, 8)).sum().backward()
+    assert all(p.grad.data_ptr() == ptrs[n] for n, p in lin.named_parameters())
+    assert float(arena.grads[torch.float32].abs().sum()) > 0
+    arena.zero_()
+    assert float(lin.weight.grad.abs().sum()) == 0.0
+    lin.weight.grad = None
+    assert arena.ensure_view(lin.weight).data_ptr() == ptrs["weight"]
+
+
+def test_duplicate_names_rejected():
+    p = torch.nn.Parameter(torch.zeros(3))
+    q = torch.nn.Parameter(torch.zeros(3))
+    with pytest.raises(ValueError):
+        GradArena([("w", p), ("w", q)], 1024, 1024)
+
+
+@pytest.mark.parametrize("nesterov,wd", [(False, 0.0), (True, 1e-2), (False, 5e-5)])
+def test_fused_sgd_equals_torch_sgd(nesterov, wd):
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(16, 8), torch.nn.Linear(16, 8)
+    b.load_state_dict(a.state_dict())
+    fo = FusedSGD(a.named_parameters(), lr=0.1, momentum=0.9, weight_decay=wd, nesterov=nesterov,
+                  weight_decay_filter=lambda n, p: True)
+    to = torch.optim.SGD(b.parameters(), lr=0.1, momentum=0.9, weight_decay=wd, nesterov=nesterov)
+    for _ in range(4):
+        x = torch.randn(5, 16)
+        fo.zero_grad(); to.zero_grad()
+        a(x).pow(2).sum().backward(); b(x).pow(2).sum().backward()
+        fo.step(); to.step()
+    assert torch.allclose(a.weight, b.weight, atol=1e-6) and torch.allclose(a.bias, b.bias, atol=1e-6)
+
+
+def test_fused_sgd_default_filter_skips_1d():
+    lin = torch.nn.Linear(4, 4)
+    opt = FusedSGD(lin.named_parameters(), lr=1.0, momentum=0.0, weight_decay=0.5)
+    w0, b0 = lin.weight.detach().clone(), lin.bias.detach().clone()
+    opt.zero_grad()
+    opt.step()  # zero gradients: only weight decay acts, and only on the 2-D kernel
+    assert torch.allclose(lin.weight, w0 * 0.5) and torch.equal(lin.bias, b0)
+
+
+def test_lars_matches_numpy_reference():
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(6, 3)
+    w0, b0 = lin.weight.detach().numpy().copy(), lin.bias.detach().numpy().copy()
+    opt = FusedLARS(lin.named_parameters(), lr=0.5, momentum=0.9, weight_decay=1e-2,
+                    trust_coefficient=0.001)
+    x = torch.randn(4, 6)
+    opt.zero_grad()
+    lin(x).pow(2).sum().backward()
+    gw, gb = lin.weight.grad.numpy().copy(), lin.bias.grad.numpy().copy()
+    opt.step()
+    wn, gn = np.linalg.norm(w0), np.linalg.norm(gw)
+    ratio = 0.001 * wn / (gn + 1e-2 * wn + 1e-8)
+    v = 0.5 * ratio * (gw + 1e-2 * w0)
+    assert np.allclose(lin.weight.detach().numpy(), w0 - v, atol=1e-6)
+    assert np.allclose(lin.bias.detach().numpy(), b0 - 0.5 * gb, atol=1e-6)  # 1-D: plain SGD
+
+
+def test_optimizer_state_dict_roundtrip():
+    lin = torch.nn.Linear(4, 2)
+    opt = FusedSGD(lin.named_parameters(), lr=0.1, momentum=0.9)
+    opt.zero_grad(); lin(torch.randn(3, 4)).sum().backward(); opt.step()
+    state = opt.state_dict()
+    lin2 = torch.nn.Linear(4, 2)
+    opt2 = FusedSGD(lin2.named_parameters(), lr=0.3, momentum=0.9)
+    opt2.load_state_dict(state)
+    assert opt2.param_groups[0]["lr"] == 0.1
+    for dt in opt.momentum_buf:
+        assert torch.equal(opt.momentum_buf[dt], opt2.momentum_buf[dt])
+
+
+def test_lr_math():
+    assert scaled_lr(0.001, 8) == 0.008
+    assert staircase_multiplier(29) == 1.0 and staircase_multiplier(30) == pytest.approx(0.1)
+    assert staircase_multiplier(85) == pytest.approx(1e-3)
+    # Goyal warm-up: lr/size at epoch 0 -> lr at warmup end
+    assert goyal_lr(0.0, 0.1, 8, warmup_epochs=5) < goyal_lr(5.0, 0.1, 8, warmup_epochs=5)
+    assert goyal_lr(45.0, 0.1, 8) == pytest.approx(goyal_lr(10.0, 0.1, 8) * 0.1)
+    assert cb.warmup_multiplier(0.0, 5, 8) == pytest.approx(1 / 8)
+    assert cb.warmup_multiplier(5.0, 5, 8) == 1.0
+    assert cb.warmup_multiplier(2.5, 5, 8) == pytest.approx(1 / 8 * (2.5 * 7 / 5 + 1))
+    assert poly_lr(0, 100, 1.0, warmup_steps=10) < poly_lr(10, 100, 1.0, warmup_steps=10)
+    assert poly_lr(100, 100, 1.0) == pytest.approx(0.0)
+
+
+def test_warmup_and_schedule_callbacks_drive_optimizer():
+    lin = torch.nn.Linear(2, 2)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.8, momentum=0.9)
+    cbs = cb.CallbackList([cb.LearningRateWarmupCallback(warmup_epochs=2, size=8),
+                           cb.LearningRateScheduleCallback(1.0, start_epoch=2, end_epoch=4),
+                           cb.LearningRateScheduleCallback(0.1, start_epoch=4)],
+                          lin, opt, steps_per_epoch=4)
+    cbs.on_train_begin({})
+    seen = []
+    for epoch in range(6):
+        cbs.on_epoch_begin(epoch, {})
+        for b in range(4):
+            cbs.on_batch_begin(b, {})
+            seen.append(opt.param_groups[0]["lr"])
+            cbs.on_batch_end(b, {})
+            assert opt.param_groups[0]["momentum"] == 0.9  # momentum correction is per step
+        cbs.on_epoch_end(epoch, {})
+    assert seen[0] == pytest.approx(0.8 / 8 * (0.25 * 7 / 2 + 1))
+    assert seen[7] == pytest.approx(0.8)            # last warm-up batch lands on the target
+    assert seen[8] == pytest.approx(0.8) and seen[16] == pytest.approx(0.08)
+    assert all(b >= a - 1e-12 for a, b in zip(seen[:8], seen[1:8]))
+
+
+def test_default_imagenet_schedule_shape():
+    sched = cb.default_imagenet_schedule()
+    assert len(sched) == 5 and isinstance(sched[0], cb.LearningRateWarmupCallback)
+
+
+def test_compression_roundtrip():
+    t = torch.randn(100)
+    for comp in (Compression.none, Compression.fp16, Compression.bf16):
+        wire, ctx = comp.compress(t)
+        back = comp.decompress(wire, ctx)
+        assert back.dtype == t.dtype and torch.allclose(back, t, atol=2e-2)
+    w, _ = Compression.fp16.compress(t)
+    assert w.dtype == torch.float16

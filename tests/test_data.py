@@ -1,0 +1,90 @@
+"""L1 data: FakeData semantics, samplers, synthetic loader, image folder."""
+import numpy as np
+import pytest
+import torch
+
+from distributeddeeplearning_amd.data import (DeviceSyntheticLoader, FakeBatchIterator, FakeData,
+                                              ShardedSampler, get_sampler)
+from distributeddeeplearning_amd.data import imagenet
+
+
+def test_fakedata_pool_and_index_map():
+    ds = FakeData(n_classes=1000, length=5000, dim=(8, 8))
+    assert len(ds) == 5000 and ds.pool_size == 32 * 20  # reference pool: batch 32 x 20 batches
+    x, y = ds[17]
+    assert x.shape == (3, 8, 8) and x.dtype == torch.float32 and 0 <= y < 1000
+    assert float(x.min()) >= 0.0 and float(x.max()) < 1.0
+    # deterministic (every rank builds the identical pool, reference :162-166)
+    ds2 = FakeData(n_classes=1000, length=5000, dim=(8, 8))
+    assert torch.equal(ds[123][0], ds2[123][0]) and ds[123][1] == ds2[123][1]
+    # index map reuses pool entries
+    j = ds.translation_index
+    assert j.min() >= 0 and j.max() < ds.pool_size and len(np.unique(j)) <= ds.pool_size
+
+
+def test_fakedata_default_length_is_imagenet():
+    from distributeddeeplearning_amd.utils.config import IMAGENET_TRAIN_LEN
+
+    assert IMAGENET_TRAIN_LEN == 1281167
+
+
+def test_fake_batch_iterator_keras_semantics():
+    it = FakeBatchIterator(batch_size=4, num_batches=3, dim=(8, 8), n_classes=10, length=10)
+    assert len(it) == 3
+    x, y = it[0]
+    assert x.shape == (4, 8, 8, 3) and y.shape == (4, 10) and torch.all(y.sum(1) == 1)
+    assert sum(1 for _ in it) == 3
+
+
+def test_sharded_sampler_partitions_and_reshuffles():
+    ds = list(range(103))
+    shards = [list(ShardedSampler(ds, num_replicas=4, rank=r, seed=1)) for r in range(4)]
+    assert all(len(s) == 26 for s in shards)  # ceil(103/4), padded like torch's sampler
+    assert set(sum(shards, [])) == set(range(103))
+    s = ShardedSampler(ds, num_replicas=4, rank=0, seed=1)
+    a = list(s)
+    s.set_epoch(1)
+    assert list(s) != a
+    with pytest.raises(ValueError):
+        ShardedSampler(ds, num_replicas=2, rank=2)
+
+
+def test_get_sampler_non_distributed_is_random_permutation():
+    s = get_sampler(list(range(10)), False, seed=3)
+    assert sorted(s) == list(range(10))
+
+
+def test_device_synthetic_loader_cpu():
+    ld = DeviceSyntheticLoader(4, length=40, pool_size=8, height=8, width=8, device="cpu",
+                               dtype=torch.float32, rank=1, world=2)
+    assert len(ld) == 5  # ceil(ceil(40/2)/4)
+    batches = list(ld)
+    assert len(batches) == 5
+    x, y = batches[0]
+    assert x.shape == (4, 3, 8, 8) and x.stride(1) == 1  # NCHW view of NHWC storage
+    assert y.dtype == torch.int64 and int(y.max()) < 1000
+
+
+def test_image_folder_and_transforms(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    for cls in ("n01", "n02"):
+        (tmp_path / cls).mkdir()
+        for i in range(3):
+            PIL.fromarray((np.random.rand(40, 50, 3) * 255).astype("uint8")).save(
+                tmp_path / cls / ("%d.png" % i))
+    ds = imagenet.ImageFolder(str(tmp_path), imagenet.train_transform(16))
+    assert len(ds) == 6 and ds.classes == ["n01", "n02"]
+    x, y = ds[4]
+    assert x.shape == (3, 16, 16) and y == 1
+    v = imagenet.ImageFolder(str(tmp_path), imagenet.val_transform(20, 16))
+    assert v[0][0].shape == (3, 16, 16)
+    with pytest.raises(FileNotFoundError):
+        imagenet.ImageFolder(str(tmp_path / "missing"))
+
+
+def test_csv_dataset(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    PIL.fromarray(np.zeros((8, 8, 3), dtype="uint8")).save(tmp_path / "a.png")
+    (tmp_path / "train.csv").write_text("filenames,num_id\na.png,7\n")
+    ds = imagenet.CsvImageDataset(str(tmp_path / "train.csv"))
+    assert len(ds) == 1 and ds[0][1] == 6  # labels are 1-based in the file (reference :98-132)

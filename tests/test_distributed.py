@@ -1,0 +1,137 @@
+"""Multi-process CPU tests over gloo, np=2, spawned with the in-repo launcher on localhost
+(mirrors the reference's ``mpirun -np 2 -H localhost:2`` smoke run; SURVEY §4, BASELINE.json
+config 1)."""
+import io
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from distributeddeeplearning_amd.launch import run as ddlrun
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+WORKER = os.path.join(HERE, "dist_worker.py")
+
+
+def _launch(scenario, np_total=2, exports=None, timeout=240):
+    sink = io.StringIO()
+    env = {"HVD_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}
+    env.update(exports or {})
+    rc = ddlrun.launch([sys.executable, "-u", WORKER, scenario], np_total,
+                       hosts=[("localhost", np_total)], exports=env, timeout=timeout, sink=sink)
+    out = sink.getvalue()
+    results = {}
+    for line in out.splitlines():
+        if "RESULT " in line:
+            rec = json.loads(line.split("RESULT ", 1)[1])
+            results[rec["rank"]] = rec
+    return rc, results, out
+
+
+def test_collectives_np2():
+    rc, res, out = _launch("collectives")
+    assert rc == 0, out
+    assert set(res) == {0, 1}
+    for r in (0, 1):
+        rec = res[r]
+        assert rec["size"] == 2 and rec["local_rank"] == r
+        assert rec["avg"] == [1.5] * 5 and rec["sum"] == [3.0] * 5 and rec["max"] == [2.0] * 5
+        assert rec["inplace"] == [1.5] * 5
+        assert rec["bcast"] == [0.0, 2.0, 4.0, 6.0]        # root 1's tensor
+        assert rec["gather"] == [0.0, 0.0, 1.0, 1.0, 1.0, 1.0]  # ragged allgather
+        assert rec["epoch"] == 7 and rec["metrics"] == [0.5, 1.0]
+        assert rec["objs"] == [0, 1] and rec["metric_average"] == 0.5
+    assert "[0]<localhost>" in out and "[1]<localhost>" in out  # per-rank output tagging
+
+
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_distributed_optimizer_equals_large_batch(fused):
+    rc, res, out = _launch("optimizer_equivalence", exports={"TEST_FUSED": fused})
+    assert rc == 0, out
+    p0, p1 = torch.tensor(res[0]["params"]), torch.tensor(res[1]["params"])
+    assert torch.equal(p0, p1)  # replicas stay identical
+    # single-process reference: batch 8, same seed
+    sys.path.insert(0, HERE)
+    import dist_worker
+
+    model = dist_worker._tiny_model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(8, 3, 8, 8, generator=g)
+    y = torch.randint(0, 5, (8,), generator=g)
+    model.train()
+    model[1].eval()
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        opt.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert torch.allclose(p0, ref, atol=2e-6), float((p0 - ref).abs().max())
+    assert "bucket 0" in res[0]["buckets"]
+
+
+def test_checkpoint_rank0_only_and_resume(tmp_path):
+    rc, res, out = _launch("checkpoint_resume", exports={"TEST_CKPT_DIR": str(tmp_path)})
+    assert rc == 0, out
+    assert res[0]["wrote"] is True and res[1]["wrote"] is False
+    for r in (0, 1):
+        assert res[r]["epoch"] == 3 and res[r]["max_diff"] == 0.0
+        assert res[r]["files"] == ["checkpoint-3.pt"] and res[r]["mom_norm"] > 0
+    payload = torch.load(tmp_path / "checkpoint-3.pt", weights_only=True)
+    assert payload["epoch"] == 3 and "0.weight" in payload["model"] and "optimizer" in payload
+
+
+def test_rank_death_kills_job_not_hangs():
+    rc, res, out = _launch("fault", exports={"HVD_FAULT_INJECT": "1:2",
+                                             "HVD_COLLECTIVE_TIMEOUT_S": "20"}, timeout=120)
+    assert rc != 0
+    assert "terminating the job" in out
+    assert 1 not in res
+
+
+def test_debug_mode_detects_shape_mismatch():
+    rc, res, out = _launch("mismatch", timeout=120)
+    assert res and all(r["raised"] for r in res.values()), out
+
+
+def test_cli_mpirun_style_flags(tmp_path):
+    script = tmp_path / "p.py"
+    script.write_text("import os; print('R', os.environ['RANK'], os.environ['WORLD_SIZE'], "
+                      "os.environ['FOO'], os.environ['OMPI_COMM_WORLD_LOCAL_RANK'])")
+    cmd = [sys.executable, "-m", "distributeddeeplearning_amd.launch.run", "-np", "2",
+           "-H", "localhost:2", "-bind-to", "none", "-map-by", "slot", "-mca", "btl", "^openib",
+           "--allow-run-as-root", "-x", "FOO=bar", sys.executable, str(script)]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert "R 0 2 bar 0" in out.stdout and "R 1 2 bar 1" in out.stdout
+
+
+def test_host_parsing_and_slot_mapping(tmp_path):
+    assert ddlrun.parse_hosts("a:2,b:4") == [("a", 2), ("b", 4)]
+    hf = tmp_path / "hosts"
+    hf.write_text("# nodes\nn0 slots=4\nn1 slots=4\n")
+    hosts = ddlrun.parse_hostfile(str(hf))
+    place = ddlrun.assign_slots(hosts, 6)
+    assert [(r, h, lr) for r, h, lr, _ in place] == [(0, "n0", 0), (1, "n0", 1), (2, "n0", 2),
+                                                      (3, "n0", 3), (4, "n1", 0), (5, "n1", 1)]
+    with pytest.raises(ValueError):
+        ddlrun.assign_slots(hosts, 9)
+
+
+def test_resnet50_gloo_np2_batch4_example():
+    """BASELINE.json config 1: ResNet-50 on synthetic 224x224 data, CPU/gloo np=2, batch 4 per
+    worker, through the reference-equivalent training script."""
+    sink = io.StringIO()
+    env = {"HVD_BACKEND": "gloo", "DISTRIBUTED": "True", "FAKE": "True", "EPOCHS": "1",
+           "FAKE_DATA_LENGTH": "16", "BATCHSIZE": "4", "OMP_NUM_THREADS": "2", "LOG_INTERVAL": "1"}
+    rc = ddlrun.launch([sys.executable, "-u", os.path.join(ROOT, "examples", "imagenet_pytorch.py")],
+                       2, hosts=[("localhost", 2)], exports=env, timeout=600, sink=sink)
+    out = sink.getvalue()
+    assert rc == 0, out[-3000:]
+    assert "Total images/sec:" in out and "Num GPUs:         2.000" in out
+    assert "Batch size:       (Per GPU 4: Total 8)" in out
+    assert out.count("Runnin Distributed") == 2
