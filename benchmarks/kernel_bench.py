@@ -86,8 +86,11 @@ def main():
                                stats=stats)
 
         def dgrad():
-            kernels.conv_igemm(dy, geom_dy, wt, dx, cin, k, k, 1, k - 1 - pad, k - 1 - pad, stride,
-                               hin, hin)
+            if k == 1 and stride == 2:  # hot path: compact GEMM, scattered by the next kernel
+                hip_ops._conv_dgrad_1x1s2_compact(dy, w)
+            else:
+                kernels.conv_igemm(dy, geom_dy, wt, dx, cin, k, k, 1, k - 1 - pad, k - 1 - pad,
+                                   stride, hin, hin)
 
         dw = torch.empty_like(w)
 

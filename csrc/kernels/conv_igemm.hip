@@ -36,6 +36,8 @@ struct IGemmParams {
     int Hout, Wout, N, M;
     int R, S, ostride, pad, pad_w, idil_log2;
     int tiles_m, tiles_n;
+    int addend_sub2;  // addend is [B][Hout/2][Wout/2][N]: added at even (h, w) pixels only
+    int parity, tiles_per_class, Mc;  // stride-2 backward-data: M ordered by output-pixel parity class
 };
 
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -75,7 +77,20 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int n0 = tile_n * BN;
+    // Parity mode (backward-data of a stride-2 conv): the input gradient is dy dilated by 2, so
+    // an output pixel (hi, wi) only sees taps with r = (pad + hi) mod 2, s = (pad_w + wi) mod 2.
+    // Rows are ordered by parity class (hi & 1, wi & 1): a tile has ONE class, walks only its
+    // live taps (9 instead of 36 tap visits over the four classes of a 3x3) and skips the rest.
+    int m0 = tile_m * BM, pcls = 0, ph = 0, pw = 0, m_lim = p.M;
+    if (p.parity) {
+        pcls = tile_m / p.tiles_per_class;
+        m0 = (tile_m - pcls * p.tiles_per_class) * BM;
+        ph = pcls >> 1; pw = pcls & 1;
+        m_lim = p.Mc;
+    }
+    const int tstep = p.parity ? 2 : 1;
+    const int r0 = p.parity ? ((p.pad + ph) & 1) : 0, s0 = p.parity ? ((p.pad_w + pw) & 1) : 0;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
@@ -85,13 +100,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     // per-row A state
     long long a_base[A_LOADS];
     int a_h0[A_LOADS], a_w0[A_LOADS];
-    const int hw = p.Hout * p.Wout;
+    const int Wq = p.parity ? (p.Wout >> 1) : p.Wout;
+    const int hw = p.parity ? (p.Hout >> 1) * Wq : p.Hout * p.Wout;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         int m = m0 + row0 + i * RPP;
-        if (m < p.M) {
+        if (m < m_lim) {
             int b = m / hw, rem = m - b * hw;
-            int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+            int ho = rem / Wq, wo = rem - ho * Wq;
+            if (p.parity) { ho = 2 * ho + ph; wo = 2 * wo + pw; }
             a_h0[i] = ho * p.ostride - p.pad;
             a_w0[i] = wo * p.ostride - p.pad_w;
             a_base[i] = (long long)b * p.xs_b + ch * 8;
@@ -109,11 +126,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 
     const int idil_mask = (1 << p.idil_log2) - 1;
     const int cpt = p.C / BK;          // K tiles per filter tap
-    const int KT = p.R * p.S * cpt;
-    int kr = 0, ks = 0, kc = 0;        // tap / channel-block counters of the tile being fetched
+    const int nr = r0 < p.R ? (p.R - r0 + tstep - 1) / tstep : 0;
+    const int ns = s0 < p.S ? (p.S - s0 + tstep - 1) / tstep : 0;
+    const int KT = nr * ns * cpt;
+    int kr = r0, ks = s0, kc = 0;      // tap / channel-block counters of the tile being fetched
 
     u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
-    auto fetch = [&](int kt) {
+    auto fetch = [&](int) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             int th = a_h0[i] + kr, tw = a_w0[i] + ks;
@@ -123,10 +142,11 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
             long long e = a_base[i] + (long long)hi * p.xs_h + (long long)wi * p.xs_w + kc * BK;
             a_reg[i] = buf_load16(xr, ok ? (unsigned)(e * 2) : 0x80000000u);
         }
+        const unsigned wk = (unsigned)(((kr * p.S + ks) * p.C + kc * BK) * 2);
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
-            b_reg[i] = buf_load16(wr, b_off[i] == 0x80000000u ? b_off[i] : b_off[i] + (unsigned)kt * (BK * 2));
-        if (++kc == cpt) { kc = 0; if (++ks == p.S) { ks = 0; ++kr; } }
+            b_reg[i] = buf_load16(wr, b_off[i] == 0x80000000u ? b_off[i] : b_off[i] + wk);
+        if (++kc == cpt) { kc = 0; ks += tstep; if (ks >= p.S) { ks = s0; kr += tstep; } }
     };
     auto stash = [&](int stage) {
         unsigned char* As = smem + stage * STAGE;
@@ -196,12 +216,28 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     for (int it = 0; it < OITER; ++it) {
         int row = orow0 + it * ORPP, m = m0 + row;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OSTR + oc * 16);
-        if (m < p.M && n < p.N) {
+        if (m < m_lim && n < p.N) {
+            if (p.parity) {  // class-local row -> pixel row of the output image
+                int b = m / hw, rem = m - b * hw;
+                int hh = rem / Wq, wh = rem - hh * Wq;
+                m = (b * p.Hout + 2 * hh + ph) * p.Wout + 2 * wh + pw;
+            }
             long long o = (long long)m * p.N + n;
             if (ADDEND) {
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(p.addend + o);
+                long long ao = o;
+                bool has = true;
+                if (p.addend_sub2) {
+                    int img = p.Hout * p.Wout;
+                    int b = m / img, rem = m - b * img;
+                    int hi = rem / p.Wout, wi = rem - hi * p.Wout;
+                    has = ((hi | wi) & 1) == 0;
+                    ao = ((long long)(b * (p.Hout >> 1) + (hi >> 1)) * (p.Wout >> 1) + (wi >> 1)) * p.N + n;
+                }
+                if (has) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8*>(p.addend + ao);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(a[e]));
+                    for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(a[e]));
+                }
             }
             *reinterpret_cast<bf16x8*>(p.y + o) = v;
             if (STATS) {
@@ -254,7 +290,7 @@ extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void*
                               long long x_numel, long long w_numel,
                               int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
                               int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
-                              hipStream_t stream) {
+                              int addend_sub2, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || N <= 0 || R <= 0 || S <= 0) return DDL_EINVAL;
     if (C % 32 != 0 || N % 8 != 0) return DDL_EINVAL;
     if (idil != 1 && idil != 2 && idil != 4) return DDL_EINVAL;
@@ -281,7 +317,16 @@ extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void*
     p.Hout = Hout; p.Wout = Wout; p.N = N; p.M = (int)M;
     p.R = R; p.S = S; p.ostride = ostride; p.pad = pad; p.pad_w = pad_w;
     p.idil_log2 = idil == 1 ? 0 : (idil == 2 ? 1 : 2);
+    if (addend_sub2 && (!addend || (Hout & 1) || (Wout & 1))) return DDL_EINVAL;
+    p.addend_sub2 = addend_sub2;
     p.tiles_m = (int)((M + 127) / 128);
+    p.parity = 0; p.tiles_per_class = 0; p.Mc = 0;
+    if (idil == 2 && ostride == 1 && (Hout % 2) == 0 && (Wout % 2) == 0 && !stats) {
+        p.parity = 1;
+        p.Mc = (int)(M / 4);
+        p.tiles_per_class = (p.Mc + 127) / 128;
+        p.tiles_m = 4 * p.tiles_per_class;
+    }
     const bool bk64 = (C % 64 == 0);
     if (N <= 64) {
         p.tiles_n = (N + 63) / 64;

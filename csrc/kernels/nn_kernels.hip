@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
 __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, int C, long long M,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/) {
+                                                              float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/, int accumulate) {
     __shared__ float a1[16][64], a2[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __re
         for (int l = 1; l < 16; ++l) { s1 += a1[l][tx]; s2 += a2[l][tx]; }
         float mu = mean[c], inv = invstd[c];
         float dg = inv * (s2 - mu * s1);
-        dgamma[c] = dg; dbeta[c] = s1;
+        if (accumulate) { dgamma[c] += dg; dbeta[c] += s1; } else { dgamma[c] = dg; dbeta[c] = s1; }
         float invM = 1.f / (float)M;
         float ca = gamma[c] * inv;
         float cb = -ca * inv * dg * invM;
@@ -583,10 +583,10 @@ extern "C" int ddl_bn_bwd_reduce(const void* dz, const void* y, const void* z, v
 }
 
 extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long M, const void* gamma, const void* mean,
-                                   const void* invstd, void* dgamma, void* dbeta, void* coef, hipStream_t stream) {
+                                   const void* invstd, void* dgamma, void* dbeta, void* coef, int accumulate, hipStream_t stream) {
     CHK(partial && gamma && mean && invstd && dgamma && dbeta && coef && G > 0 && C > 0 && M > 0, DDL_EINVAL);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, G, C, M,
-                       (const float*)gamma, (const float*)mean, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
+                       (const float*)gamma, (const float*)mean, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef, accumulate);
     return ddl_launch_status();
 }
 

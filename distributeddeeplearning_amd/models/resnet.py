@@ -95,6 +95,24 @@ def _cba(conv, bn, x, residual=None):
                            bn.relu, residual)
 
 
+def _unit(conv, bn):
+    if bn.training:
+        bn.num_batches_tracked += 1
+    return (conv.weight, conv.stride, conv.padding, bn.weight, bn.bias, bn.running_mean,
+            bn.running_var)
+
+
+def _block(x, pairs, downsample):
+    """Run a residual block through ``ops.residual_block`` (one fused autograd node on GPU)."""
+    bn0 = pairs[0][1]
+    units = [_unit(c, b) for c, b in pairs]
+    ds = None
+    if downsample is not None:
+        u = _unit(downsample[0], downsample[1])
+        ds = (u[0], u[1]) + u[3:]
+    return ops.residual_block(x, units, ds, bn0.training, bn0.momentum, bn0.eps)
+
+
 class Linear(nn.Module):
     def __init__(self, cin, cout):
         super().__init__()
@@ -129,10 +147,8 @@ class Bottleneck(nn.Module):
         self.downsample = _Downsample(cin, filters * 4, stride) if project else None
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        out = _cba(self.conv1, self.bn1, x)
-        out = _cba(self.conv2, self.bn2, out)
-        return _cba(self.conv3, self.bn3, out, shortcut)
+        return _block(x, [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)],
+                      self.downsample)
 
 
 class BasicBlock(nn.Module):
@@ -147,9 +163,7 @@ class BasicBlock(nn.Module):
         self.downsample = _Downsample(cin, filters, stride) if project else None
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        out = _cba(self.conv1, self.bn1, x)
-        return _cba(self.conv2, self.bn2, out, shortcut)
+        return _block(x, [(self.conv1, self.bn1), (self.conv2, self.bn2)], self.downsample)
 
 
 class ResNet(nn.Module):

@@ -24,7 +24,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-__all__ = ["use_hip", "conv2d", "conv_bn_act", "batchnorm_act", "maxpool3x3s2", "global_avgpool", "linear",
+__all__ = ["use_hip", "conv2d", "conv_bn_act", "residual_block", "batchnorm_act", "maxpool3x3s2", "global_avgpool", "linear",
            "softmax_cross_entropy", "topk_correct", "set_backend", "backend"]
 
 _FORCED = os.environ.get("DDL_OPS", "auto").lower()  # auto | hip | aten
@@ -94,6 +94,31 @@ def conv_bn_act(x, weight, stride, padding, gamma, beta, running_mean, running_v
     y = conv2d(x, weight, stride, padding)
     return batchnorm_act(y, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
                          residual)
+
+
+def residual_block(x, units, downsample, training, momentum=0.1, eps=1e-5):
+    """A whole residual block: ``units`` is the main path as a list of
+    ``(weight, stride, padding, gamma, beta, running_mean, running_var)`` conv-BN-ReLU pairs (the
+    last one adds the shortcut before its ReLU), ``downsample`` is None (identity shortcut) or
+    ``(weight, stride, gamma, beta, running_mean, running_var)`` for the 1x1 projection
+    (``HorovodTF/src/resnet_model.py:112-204``).  On the HIP path the block is one autograd
+    node with a hand-scheduled backward (``hip_ops.ResidualBlockFn``)."""
+    if use_hip(x):
+        from . import hip_ops
+
+        convs = [u[0] for u in units] + ([downsample[0]] if downsample is not None else [])
+        if hip_ops.residual_block_supported(convs):
+            return hip_ops.residual_block(x, units, downsample, training, momentum, eps)
+    shortcut = x
+    if downsample is not None:
+        w, s, g, b, rm, rv = downsample
+        shortcut = conv_bn_act(x, w, s, 0, g, b, rm, rv, training, momentum, eps, False)
+    cur = x
+    for i, (w, s, p, g, b, rm, rv) in enumerate(units):
+        last = i == len(units) - 1
+        cur = conv_bn_act(cur, w, s, p, g, b, rm, rv, training, momentum, eps, True,
+                          shortcut if last else None)
+    return cur
 
 
 def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,

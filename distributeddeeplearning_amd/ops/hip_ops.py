@@ -142,7 +142,8 @@ def _is_stem(w, stride, padding):
         stride == 2 and padding == 3
 
 
-def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho, Wo, n_valid=None):
+def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho, Wo, n_valid=None,
+                accumulate=False):
     """Backward-weights: split-K partials then ordered reduction into a tensor shaped like
     ``w_like`` (memory [K][R][S][C])."""
     B, Hin, Win, C = geom[0], geom[1], geom[2], geom[3]
@@ -152,8 +153,154 @@ def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho
     partial = torch.empty((splits, slab), dtype=torch.float32, device=dy.device)
     K.conv_wgrad(dy, x_ptr_tensor, geom, partial, Kc, R, S, stride, pad, pad_w, Ho, Wo, splits)
     n = slab if n_valid is None else n_valid
-    K.splitk_reduce(partial, w_like, n, splits, slab)
+    K.splitk_reduce(partial, w_like, n, splits, slab, accumulate)
     return w_like
+
+
+# ---- gradient sinks --------------------------------------------------------------------------
+# A fused block writes weight gradients straight into ``param.grad`` (the flat gradient arena of
+# parallel.bucket.GradArena: wgrad output lands in the all-reduce buffer, no extra add pass) and
+# returns None to autograd for them; listeners (DistributedOptimizer) are told which parameter
+# just became ready, which is what autograd's post-accumulate hook would have done.
+_grad_listeners = []
+
+
+def add_grad_listener(fn):
+    if fn not in _grad_listeners:
+        _grad_listeners.append(fn)
+
+
+def remove_grad_listener(fn):
+    if fn in _grad_listeners:
+        _grad_listeners.remove(fn)
+
+
+def _direct_grad_ok(p):
+    g = p.grad
+    return g is not None and g.dtype in (torch.float32, _BF16) and g.shape == p.shape and \
+        g.stride() == p.stride() and g.data_ptr() % 16 == 0
+
+
+def _notify(p):
+    for fn in _grad_listeners:
+        fn(p)
+
+
+# ---- raw (autograd-free) building blocks -------------------------------------------------------
+def _conv_fwd(x, w, stride, padding, want_stats):
+    B, C, H, W = x.shape
+    Kc, Cw, R, S = w.shape
+    if Cw != C:
+        raise K.KernelError("conv: input has %d channels, weight expects %d" % (C, Cw))
+    Ho = (H + 2 * padding - R) // stride + 1
+    Wo = (W + 2 * padding - S) // stride + 1
+    y = _empty_nhwc(B, Kc, Ho, Wo, x.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty((K.conv_tiles_m(B * Ho * Wo), 2, Kc), dtype=torch.float32,
+                            device=x.device)
+    K.conv_igemm(x, _geom(x), w, y, Kc, R, S, stride, padding, padding, 1, Ho, Wo, stats=stats)
+    return y, stats
+
+
+def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False):
+    B, C, H, W = x_shape
+    _, _, R, S = w.shape
+    wt = _WT.get(w)
+    if R == 1 and S == 1 and stride == 2 and padding == 0 and addend is None:
+        # 1x1 stride 2: only even pixels receive a gradient; compute them as a plain GEMM and
+        # scatter (the fused block never gets here: it hands the compact result to the next
+        # backward-data kernel as a sub-sampled addend)
+        dx = torch.zeros((B, C, H, W), dtype=_BF16, device=dy.device).contiguous(memory_format=_CL)
+        dx[:, :, ::2, ::2] = _conv_dgrad_1x1s2_compact(dy, w)
+        return dx
+    dx = _empty_nhwc(B, C, H, W, dy.device)
+    K.conv_igemm(dy, _geom(dy), wt, dx, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
+                 addend=addend, addend_sub2=addend_sub2)
+    return dx
+
+
+def _conv_dgrad_1x1s2_compact(dy, w):
+    """Gradient of a 1x1 / stride 2 conv at the even input pixels only: [B, Cin, Ho, Wo]."""
+    B, Kc, Ho, Wo = dy.shape
+    C = w.shape[1]
+    wt = _WT.get(w)
+    out = _empty_nhwc(B, C, Ho, Wo, dy.device)
+    K.conv_igemm(dy, _geom(dy), wt, out, C, 1, 1, 1, 0, 0, 1, Ho, Wo)
+    return out
+
+
+def _conv_wgrad(dy, x, w, stride, padding):
+    """dw for ``w``: written into ``w.grad`` when that is a live arena view (returns None and
+    notifies the listeners), otherwise returned as a new tensor."""
+    Kc, _, R, S = w.shape
+    Ho, Wo = dy.shape[2], dy.shape[3]
+    if _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]:
+        _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
+                    accumulate=True)
+        _notify(w)
+        return None
+    return _wgrad_into(dy, x, _geom(x), torch.empty_like(w), Kc, R, S, stride, padding, padding,
+                       Ho, Wo)
+
+
+_DIRECT = {"on": False}
+
+
+def _bn_fwd(y, gamma, beta, residual, stats, rmean, rvar, training, momentum, eps, relu):
+    B, C, H, W = y.shape
+    M = B * H * W
+    dev = y.device
+    coeffs = torch.empty((4, C), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+    if training:
+        if stats is None or stats.numel() == 0:
+            rows = 512
+            T = (M + rows - 1) // rows
+            stats = torch.empty((T, 2, C), dtype=torch.float32, device=dev)
+            K.bn_stats_partial(y, stats, M, C, rows)
+        else:
+            rows, T = 128, stats.shape[0]
+        K.bn_fwd_finalize(stats, T, C, M, rows, gamma, beta, rmean, rvar, momentum, eps,
+                          coeffs[0], coeffs[1], coeffs[2], coeffs[3])
+    else:
+        K.bn_eval_coeffs(gamma, beta, rmean, rvar, eps, coeffs[2], coeffs[3])
+    z = torch.empty_like(y)
+    K.bn_apply_fwd(y, coeffs[2], coeffs[3], residual, z, M, C, relu)
+    return z, coeffs
+
+
+def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None):
+    """(dy, dgamma, dbeta, g) with g = dz masked by the ReLU (None unless want_g and relu).
+
+    With ``beta`` given and direct gradients enabled, dgamma/dbeta are accumulated by the
+    finalize kernel straight into ``gamma.grad`` / ``beta.grad`` (returned as None)."""
+    B, C, H, W = y.shape
+    M = B * H * W
+    dev = y.device
+    G = K.bn_bwd_blocks(M)
+    partial = torch.empty((G, 2, C), dtype=torch.float32, device=dev)
+    K.bn_bwd_reduce(dz, y, z, partial, M, C, relu, G)
+    coef = torch.empty((3, C), dtype=torch.float32, device=dev)
+    direct = beta is not None and _DIRECT["on"] and _direct_grad_ok(gamma) and \
+        _direct_grad_ok(beta) and gamma.grad.dtype == torch.float32 and \
+        beta.grad.dtype == torch.float32
+    if direct:
+        K.bn_bwd_finalize(partial, G, C, M, gamma, coeffs[0], coeffs[1], gamma.grad, beta.grad,
+                          coef, accumulate=True)
+        dg = db = None
+    else:
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        K.bn_bwd_finalize(partial, G, C, M, gamma, coeffs[0], coeffs[1], dgb[0], dgb[1], coef)
+        dg, db = dgb[0], dgb[1]
+    dy = torch.empty_like(y)
+    g = torch.empty_like(y) if (want_g and relu) else None
+    K.bn_bwd_apply(dz, y, z, coef, dy, g, M, C, relu)
+    if want_g and not relu:
+        g = dz
+    if direct:
+        _notify(gamma)
+        _notify(beta)
+    return dy, dg, db, g
 
 
 class ConvFn(Function):
@@ -164,18 +311,7 @@ class ConvFn(Function):
         x = _as_nhwc(x)
         if not _krsc_ok(w):
             raise K.KernelError("conv weight must be channels_last (KRSC) in memory")
-        B, C, H, W = x.shape
-        Kc, Cw, R, S = w.shape
-        if Cw != C:
-            raise K.KernelError("conv: input has %d channels, weight expects %d" % (C, Cw))
-        Ho = (H + 2 * padding - R) // stride + 1
-        Wo = (W + 2 * padding - S) // stride + 1
-        y = _empty_nhwc(B, Kc, Ho, Wo, x.device)
-        stats = None
-        if want_stats:
-            stats = torch.empty((K.conv_tiles_m(B * Ho * Wo), 2, Kc), dtype=torch.float32,
-                                device=x.device)
-        K.conv_igemm(x, _geom(x), w, y, Kc, R, S, stride, padding, padding, 1, Ho, Wo, stats=stats)
+        y, stats = _conv_fwd(x, w, stride, padding, want_stats)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding)
         if stats is None:
@@ -188,18 +324,13 @@ class ConvFn(Function):
         x, w = ctx.saved_tensors
         stride, padding = ctx.cfg
         dy = _as_nhwc(dy)
-        B, C, H, W = x.shape
-        Kc, _, R, S = w.shape
-        Ho, Wo = dy.shape[2], dy.shape[3]
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = _WT.get(w)
-            dx = _empty_nhwc(B, C, H, W, x.device)
-            K.conv_igemm(dy, _geom(dy), wt, dx, C, R, S, 1, R - 1 - padding, S - 1 - padding,
-                         stride, H, W)
+            dx = _conv_dgrad(dy, w, x.shape, stride, padding)
         if ctx.needs_input_grad[1]:
+            Kc, _, R, S = w.shape
             dw = _wgrad_into(dy, x, _geom(x), torch.empty_like(w), Kc, R, S, stride, padding,
-                             padding, Ho, Wo)
+                             padding, dy.shape[2], dy.shape[3])
         return dx, dw, None, None, None
 
 
@@ -284,26 +415,10 @@ class BatchNormActFn(Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, residual, stats, rmean, rvar, training, momentum, eps, relu):
         y = _as_nhwc(y)
-        B, C, H, W = y.shape
-        M = B * H * W
-        dev = y.device
-        coeffs = torch.empty((4, C), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-        if training:
-            if stats is None or stats.numel() == 0:
-                rows = 512
-                T = (M + rows - 1) // rows
-                stats = torch.empty((T, 2, C), dtype=torch.float32, device=dev)
-                K.bn_stats_partial(y, stats, M, C, rows)
-            else:
-                rows, T = 128, stats.shape[0]
-            K.bn_fwd_finalize(stats, T, C, M, rows, gamma, beta, rmean, rvar, momentum, eps,
-                              coeffs[0], coeffs[1], coeffs[2], coeffs[3])
-        else:
-            K.bn_eval_coeffs(gamma, beta, rmean, rvar, eps, coeffs[2], coeffs[3])
         if residual is not None:
             residual = _as_nhwc(residual)
-        z = torch.empty_like(y)
-        K.bn_apply_fwd(y, coeffs[2], coeffs[3], residual, z, M, C, relu)
+        z, coeffs = _bn_fwd(y, gamma, beta, residual, stats, rmean, rvar, training, momentum, eps,
+                            relu)
         ctx.relu = bool(relu)
         ctx.training = bool(training)
         ctx.has_res = residual is not None
@@ -316,30 +431,144 @@ class BatchNormActFn(Function):
             raise K.KernelError("BatchNorm backward in eval mode is not supported by the HIP path")
         y, z, gamma, coeffs = ctx.saved_tensors
         dz = _as_nhwc(dz)
-        B, C, H, W = y.shape
-        M = B * H * W
-        dev = y.device
-        G = K.bn_bwd_blocks(M)
-        partial = torch.empty((G, 2, C), dtype=torch.float32, device=dev)
-        K.bn_bwd_reduce(dz, y, z, partial, M, C, ctx.relu, G)
-        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
-        coef = torch.empty((3, C), dtype=torch.float32, device=dev)
-        K.bn_bwd_finalize(partial, G, C, M, gamma, coeffs[0], coeffs[1], dgb[0], dgb[1], coef)
-        dy = torch.empty_like(y)
-        gres = None
         want_res = ctx.has_res and ctx.needs_input_grad[3]
-        if want_res and ctx.relu:
-            gres = torch.empty_like(y)
-        K.bn_bwd_apply(dz, y, z, coef, dy, gres, M, C, ctx.relu)
-        if want_res and not ctx.relu:
-            gres = dz
-        return dy, dgb[0], dgb[1], gres, None, None, None, None, None, None, None
+        dy, dg, db, gres = _bn_bwd(dz, y, z, gamma, coeffs, ctx.relu, want_res)
+        return dy, dg, db, gres, None, None, None, None, None, None, None
 
 
 def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
                   residual, stats=None):
     return BatchNormActFn.apply(x, gamma, beta, residual, stats, running_mean, running_var,
                                 training, momentum, eps, relu)
+
+
+# ----------------------------------------------------------------------------------------------
+# fused residual blocks: one autograd node per block, hand-scheduled backward
+# ----------------------------------------------------------------------------------------------
+class ResidualBlockFn(Function):
+    """A whole bottleneck (3 conv-BN pairs) or basic block (2 pairs) plus optional projection
+    shortcut as ONE autograd node (``HorovodTF/src/resnet_model.py:112-204``).
+
+    What the hand-written backward buys over autograd's composition of the per-op nodes:
+    * the shortcut gradient is added in the epilogue of the first conv's backward-data kernel
+      instead of by a separate elementwise pass over the (largest) block-input tensor;
+    * weight and BatchNorm gradients are written straight into the flat gradient arena
+      (``param.grad`` views) — the wgrad reduction's output IS the all-reduce buffer;
+    * no autograd bookkeeping between the ~30 kernels of a block.
+
+    ``units`` = number of conv-BN pairs on the main path (3 or 2); parameters arrive flat:
+    for each unit (weight, gamma, beta, running_mean, running_var), then the same five for the
+    projection shortcut when ``has_ds``.
+    """
+
+    @staticmethod
+    def forward(ctx, x, cfg, *tensors):
+        units, strides, pads, has_ds, ds_stride, training, momentum, eps = cfg
+        x = _as_nhwc(x)
+        n = units + (1 if has_ds else 0)
+        groups = [tensors[5 * i: 5 * i + 5] for i in range(n)]
+        saved_y, saved_z, saved_c = [], [], []
+        shortcut = x
+        yd = cd = None
+        if has_ds:
+            wd, gd, bd, rmd, rvd = groups[units]
+            yd, st = _conv_fwd(x, wd, ds_stride, 0, training)
+            shortcut, cd = _bn_fwd(yd, gd, bd, None, st, rmd, rvd, training, momentum, eps, False)
+        cur = x
+        for i in range(units):
+            w, g, b, rm, rv = groups[i]
+            y, st = _conv_fwd(cur, w, strides[i], pads[i], training)
+            last = i == units - 1
+            z, c = _bn_fwd(y, g, b, shortcut if last else None, st, rm, rv, training, momentum,
+                           eps, True)
+            saved_y.append(y)
+            saved_z.append(z)
+            saved_c.append(c)
+            cur = z
+        ctx.cfg = cfg
+        ctx.n_in = 2 + len(tensors)
+        ctx.params = groups  # parameters/buffers are leaves: plain references are safe
+        keep = [x] + saved_y + saved_z + saved_c
+        if has_ds:
+            keep += [yd, cd]
+        ctx.save_for_backward(*keep)
+        return cur
+
+    @staticmethod
+    def backward(ctx, dout):
+        units, strides, pads, has_ds, ds_stride, training, momentum, eps = ctx.cfg
+        if not training:
+            raise K.KernelError("fused residual block: backward in eval mode is not supported")
+        saved = ctx.saved_tensors
+        x = saved[0]
+        ys = saved[1: 1 + units]
+        zs = saved[1 + units: 1 + 2 * units]
+        cs = saved[1 + 2 * units: 1 + 3 * units]
+        groups = ctx.params
+        grads = [None] * ctx.n_in
+        dout = _as_nhwc(dout)
+
+        def put(unit, dw, dg, db):
+            base = 2 + 5 * unit
+            grads[base], grads[base + 1], grads[base + 2] = dw, dg, db
+
+        dz = dout
+        g_short = None
+        for i in range(units - 1, -1, -1):
+            w, gam, bet = groups[i][0], groups[i][1], groups[i][2]
+            last = i == units - 1
+            dy, dg, db, g = _bn_bwd(dz, ys[i], zs[i], gam, cs[i], True, last, beta=bet)
+            if last:
+                g_short = g
+            inp = zs[i - 1] if i > 0 else x
+            dw = _conv_wgrad(dy, inp, w, strides[i], pads[i])
+            put(i, dw, dg, db)
+            if i > 0:
+                dz = _conv_dgrad(dy, w, inp.shape, strides[i], pads[i])
+            else:
+                addend, sub2 = g_short, False
+                if has_ds:
+                    wd, gd, bd = groups[units][0], groups[units][1], groups[units][2]
+                    yd, cd = saved[1 + 3 * units], saved[2 + 3 * units]
+                    dyd, dgd, dbd, _ = _bn_bwd(g_short, yd, None, gd, cd, False, False, beta=bd)
+                    dwd = _conv_wgrad(dyd, x, wd, ds_stride, 0)
+                    put(units, dwd, dgd, dbd)
+                    if ctx.needs_input_grad[0]:
+                        if ds_stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+                            addend, sub2 = _conv_dgrad_1x1s2_compact(dyd, wd), True
+                        else:
+                            addend = _conv_dgrad(dyd, wd, x.shape, ds_stride, 0)
+                if ctx.needs_input_grad[0]:
+                    grads[0] = _conv_dgrad(dy, w, x.shape, strides[i], pads[i], addend=addend,
+                                           addend_sub2=sub2)
+        return tuple(grads)
+
+
+def residual_block_supported(convs):
+    return all(w.dim() == 4 and w.shape[1] % 32 == 0 and w.shape[0] % 32 == 0 and
+               bn_supported(w.shape[0]) and _krsc_ok(w) for w in convs)
+
+
+def residual_block(x, units, downsample, training, momentum, eps):
+    """``units``: list of (weight, stride, padding, gamma, beta, running_mean, running_var);
+    ``downsample``: None or (weight, stride, gamma, beta, running_mean, running_var)."""
+    tensors, strides, pads = [], [], []
+    for (w, s, p, g, b, rm, rv) in units:
+        tensors += [w, g, b, rm, rv]
+        strides.append(s)
+        pads.append(p)
+    ds_stride = 1
+    if downsample is not None:
+        w, ds_stride, g, b, rm, rv = downsample
+        tensors += [w, g, b, rm, rv]
+    cfg = (len(units), tuple(strides), tuple(pads), downsample is not None, ds_stride,
+           bool(training), float(momentum), float(eps))
+    return ResidualBlockFn.apply(x, cfg, *tensors)
+
+
+def set_direct_grads(on: bool):
+    """Let fused blocks write parameter gradients straight into ``param.grad`` arena views."""
+    _DIRECT["on"] = bool(on)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -156,14 +156,14 @@ def storage_numel_from(x):
 
 
 def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil, Hout, Wout,
-               addend=None, stats=None):
+               addend=None, stats=None, addend_sub2=False):
     """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel)."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
     check(lib().ddl_conv_igemm(ptr(x_ptr_tensor), ptr(w), ptr(y), ptr(addend), ptr(stats),
                                _i64(xn), _i64(w.numel()), _i32(B), _i32(Hin), _i32(Win), _i32(C),
                                _i64(sb), _i64(sh), _i64(sw), _i32(Hout), _i32(Wout), _i32(n_out),
                                _i32(R), _i32(S), _i32(ostride), _i32(pad), _i32(pad_w), _i32(idil),
-                               stream()), "conv_igemm")
+                               _i32(bool(addend_sub2)), stream()), "conv_igemm")
 
 
 def conv_tiles_m(M):
@@ -224,10 +224,10 @@ def bn_bwd_reduce(dz, y, z, partial, M, C, relu, G):
                                   _i32(bool(relu)), _i32(G), stream()), "bn_bwd_reduce")
 
 
-def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef):
+def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef, accumulate=False):
     check(lib().ddl_bn_bwd_finalize(ptr(partial), _i32(G), _i32(C), _i64(M), ptr(gamma), ptr(mean),
-                                    ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(coef), stream()),
-          "bn_bwd_finalize")
+                                    ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(coef),
+                                    _i32(bool(accumulate)), stream()), "bn_bwd_finalize")
 
 
 def bn_bwd_apply(dz, y, z, coef, dy, gout, M, C, relu):

@@ -77,6 +77,12 @@ class _ArenaOptimizer(Optimizer):
                            "adapt": adapt, "segments": [seg]}
                     self.runs.append(cur)
         self._step = 0
+        try:  # gradients are arena views: fused HIP blocks may accumulate into them directly
+            from ..ops import hip_ops as _hip_ops
+
+            _hip_ops.set_direct_grads(True)
+        except Exception:  # pragma: no cover
+            pass
 
     # -- helpers ---------------------------------------------------------------------------
     def _weights(self, dt):

@@ -91,6 +91,15 @@ class _DistributedMixin:
         for n, p in named:
             if p.requires_grad:
                 self._ddl_hooks.append(p.register_post_accumulate_grad_hook(self._ddl_on_grad))
+        # fused HIP blocks write gradients straight into the arena and report readiness here
+        # instead of through autograd's accumulate hook
+        try:
+            from ..ops import hip_ops as _hip_ops
+
+            _hip_ops.add_grad_listener(self._ddl_on_direct_grad)
+            _hip_ops.set_direct_grads(True)
+        except Exception:  # pragma: no cover - ops layer unavailable
+            pass
         if cfg.timeline and not _tl.enabled():
             _tl.start(cfg.timeline, _b.rank())
         if cfg.debug and _b.size() > 1:
@@ -115,6 +124,10 @@ class _DistributedMixin:
         st.pending -= 1
         if st.pending == 0 and not st.launched:
             self._ddl_launch(st)
+
+    def _ddl_on_direct_grad(self, p):
+        if id(p) in self._ddl_names:
+            self._ddl_on_grad(p)
 
     def _ddl_launch(self, st):
         st.launched = True

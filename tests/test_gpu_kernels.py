@@ -54,6 +54,8 @@ CONV_CASES = [
     (6, 512, 7, 7, 2048, 1, 1, 0),    # d5
     (2, 512, 14, 14, 512, 3, 2, 1),   # d2
     (2, 32, 9, 11, 96, 3, 1, 1),      # BK=32 path, odd sizes, Cout not a tile multiple
+    (2, 64, 15, 15, 64, 3, 2, 1),     # stride 2 with odd extent: dilated (non-parity) dgrad path
+    (3, 64, 10, 12, 128, 1, 2, 0),    # 1x1 stride 2, parity dgrad with empty tap classes
 ]
 
 
@@ -271,6 +273,46 @@ def test_bottleneck_block_matches_fp32_reference():
     ok(dx_hip, dx_at, dx_ref, "dx")
     for n in g_ref:
         ok(g_hip[n], g_at[n], g_ref[n], n)
+
+
+def test_residual_block_direct_grads_match_autograd_accumulation():
+    """Fused block writing into pre-existing ``param.grad`` arena views (direct mode) must give
+    the same gradients as returning them to autograd, and must notify the listeners once per
+    parameter."""
+    from distributeddeeplearning_amd.models.resnet import Bottleneck
+    from distributeddeeplearning_amd.parallel.bucket import GradArena
+
+    hip = _hip()
+    hip.reset_caches()
+
+    def make():
+        torch.manual_seed(3)
+        m = Bottleneck(128, 64, 1, True, False).to(DEV).train()
+        for mod in m.modules():
+            if hasattr(mod, "kernel"):
+                mod.weight.data = mod.weight.data.to(BF).contiguous(memory_format=CL)
+        return m
+
+    x = rand_nhwc(4, 128, 14, 14, seed=21)
+    g = rand_nhwc(4, 256, 14, 14, seed=22)
+    ref = make()
+    hip.set_direct_grads(False)
+    ref(x).backward(g)
+    m = make()
+    arena = GradArena(list(m.named_parameters()), 1 << 20, 1 << 20)
+    seen = []
+    listener = lambda p: seen.append(id(p))  # noqa: E731
+    hip.add_grad_listener(listener)
+    hip.set_direct_grads(True)
+    try:
+        m(x).backward(g)
+    finally:
+        hip.set_direct_grads(False)
+        hip.remove_grad_listener(listener)
+    assert sorted(seen) == sorted(id(p) for p in m.parameters())
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad.data_ptr() == arena.views[id(p)].data_ptr(), n
+        assert torch.allclose(p.grad.float(), q.grad.float(), rtol=2e-2, atol=1e-3), n
 
 
 def test_resnet50_trains_on_hip_kernels():
