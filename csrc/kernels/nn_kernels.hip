@@ -15,6 +15,10 @@ __device__ __forceinline__ void load8f(const float* p, float* v) {
     for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
 }
 
+// The one BN affine used by forward and by the backward's mask recomputation: identical
+// rounding on both sides, so "z > 0" can be re-derived from y without reading z.
+__device__ __forceinline__ float bn_affine(float v, float sc, float sh) { return __builtin_fmaf(v, sc, sh); }
+
 // ---------------------------------------------------------------------------------------------
 // K6a: standalone statistics partials [T][2][C] over tiles of `rows_per_tile` rows (used when the
 // producer is not our conv kernel).  256 threads = (C/8 chunk columns) x row lanes.
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restr
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = bf2f(v[e]) * sc[e] + sh[e];
+            float f = bn_affine(bf2f(v[e]), sc[e], sh[e]);
             if (RES) f += bf2f(r[e]);
             if (RELU) f = fmaxf(f, 0.f);
             o[e] = f2bf(f);
@@ -160,9 +164,12 @@ __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restr
 // K8a: per-block partial sums  s1[c] = sum g,  s2[c] = sum g*y,  g = dz * (z > 0) (RELU) or dz.
 // grid = G blocks over contiguous row ranges; 256 threads = C/8 chunk columns x row lanes.
 // ---------------------------------------------------------------------------------------------
-template <bool RELU>
+// MASK: 0 = no ReLU, 1 = mask from the stored activation z, 2 = mask recomputed from y with the
+// forward scale/shift (non-residual BN+ReLU: saves the read of z in both backward passes).
+template <int MASK>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
-                                                           const bf16_t* __restrict__ z, float* __restrict__ partial,
+                                                           const bf16_t* __restrict__ z, const float* __restrict__ fcoef,
+                                                           float* __restrict__ partial,
                                                            long long M, int C, long long rows_per_block) {
     __shared__ float red[2][2048];
     const int cchunks = C >> 3, rlanes = 256 / cchunks;
@@ -170,20 +177,22 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    float s1[8], s2[8];
+    float s1[8], s2[8], sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (MASK == 2) { load8f(fcoef + cc * 8, sc); load8f(fcoef + C + cc * 8, sh); }
     for (long long r = r0 + rl; r < r1; r += rlanes) {
         long long o = r * C + cc * 8;
         bf16x8 d = *reinterpret_cast<const bf16x8*>(dz + o);
         bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + o);
         bf16x8 zv;
-        if (RELU) zv = *reinterpret_cast<const bf16x8*>(z + o);
+        if (MASK == 1) zv = *reinterpret_cast<const bf16x8*>(z + o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float g = bf2f(d[e]);
-            if (RELU) g = bf2f(zv[e]) > 0.f ? g : 0.f;
-            s1[e] += g; s2[e] += g * bf2f(yv[e]);
+            float g = bf2f(d[e]), yf = bf2f(yv[e]);
+            if (MASK == 1) g = bf2f(zv[e]) > 0.f ? g : 0.f;
+            if (MASK == 2) g = bn_affine(yf, sc[e], sh[e]) > 0.f ? g : 0.f;
+            s1[e] += g; s2[e] += g * yf;
         }
     }
 #pragma unroll
@@ -227,9 +236,10 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __re
 }
 
 // K8c: dy = ca*g + cb*y + cc ; optionally also store g (gradient of the residual branch)
-template <bool RELU, bool WRITE_G>
+template <int MASK, bool WRITE_G>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
-                                                          const bf16_t* __restrict__ z, const float* __restrict__ coef,
+                                                          const bf16_t* __restrict__ z, const float* __restrict__ fcoef,
+                                                          const float* __restrict__ coef,
                                                           bf16_t* __restrict__ dy, bf16_t* __restrict__ gout,
                                                           long long nchunks, int cchunks) {
     const int C = cchunks * 8;
@@ -239,15 +249,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
         bf16x8 d = *reinterpret_cast<const bf16x8*>(dz + (i << 3));
         bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + (i << 3));
         bf16x8 zv;
-        if (RELU) zv = *reinterpret_cast<const bf16x8*>(z + (i << 3));
-        float ca[8], cb[8], c0[8];
+        if (MASK == 1) zv = *reinterpret_cast<const bf16x8*>(z + (i << 3));
+        float ca[8], cb[8], c0[8], sc[8], sh[8];
         load8f(coef + c, ca); load8f(coef + C + c, cb); load8f(coef + 2 * C + c, c0);
+        if (MASK == 2) { load8f(fcoef + c, sc); load8f(fcoef + C + c, sh); }
         bf16x8 o, go;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float g = bf2f(d[e]);
-            if (RELU) g = bf2f(zv[e]) > 0.f ? g : 0.f;
-            o[e] = f2bf(ca[e] * g + cb[e] * bf2f(yv[e]) + c0[e]);
+            float g = bf2f(d[e]), yf = bf2f(yv[e]);
+            if (MASK == 1) g = bf2f(zv[e]) > 0.f ? g : 0.f;
+            if (MASK == 2) g = bn_affine(yf, sc[e], sh[e]) > 0.f ? g : 0.f;
+            o[e] = f2bf(ca[e] * g + cb[e] * yf + c0[e]);
             if (WRITE_G) go[e] = f2bf(g);
         }
         *reinterpret_cast<bf16x8*>(dy + (i << 3)) = o;
@@ -572,13 +584,16 @@ extern "C" int ddl_bn_bwd_blocks(long long M) {
     return (int)g;
 }
 
-extern "C" int ddl_bn_bwd_reduce(const void* dz, const void* y, const void* z, void* partial, long long M, int C, int relu,
-                                 int G, hipStream_t stream) {
-    CHK(dz && y && partial && M > 0 && G > 0 && pow2_chunks_ok(C) && (!relu || z), DDL_EINVAL);
-    CHK(ddl_aligned16(dz) && ddl_aligned16(y) && (!z || ddl_aligned16(z)), DDL_EALIGN);
+// mask: 0 none, 1 from z, 2 recomputed from y with fcoef = [scale | shift] (2*C floats)
+extern "C" int ddl_bn_bwd_reduce(const void* dz, const void* y, const void* z, const void* fcoef, void* partial, long long M,
+                                 int C, int mask, int G, hipStream_t stream) {
+    CHK(dz && y && partial && M > 0 && G > 0 && pow2_chunks_ok(C), DDL_EINVAL);
+    CHK(mask == 0 || (mask == 1 && z) || (mask == 2 && fcoef), DDL_EINVAL);
+    CHK(ddl_aligned16(dz) && ddl_aligned16(y) && (!z || ddl_aligned16(z)) && (!fcoef || ddl_aligned16(fcoef)), DDL_EALIGN);
     long long rpb = (M + G - 1) / G;
-    if (relu) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (float*)partial, M, C, rpb);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (float*)partial, M, C, rpb);
+#define L(MK) hipLaunchKernelGGL(bn_bwd_reduce_kernel<MK>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (float*)partial, M, C, rpb)
+    if (mask == 1) L(1); else if (mask == 2) L(2); else L(0);
+#undef L
     return ddl_launch_status();
 }
 
@@ -590,15 +605,18 @@ extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long 
     return ddl_launch_status();
 }
 
-extern "C" int ddl_bn_bwd_apply(const void* dz, const void* y, const void* z, const void* coef, void* dy, void* gout,
-                                long long M, int C, int relu, hipStream_t stream) {
-    CHK(dz && y && coef && dy && M > 0 && C > 0 && (C & 7) == 0 && (!relu || z), DDL_EINVAL);
-    CHK(ddl_aligned16(dz) && ddl_aligned16(y) && ddl_aligned16(dy) && ddl_aligned16(coef) && (!z || ddl_aligned16(z)) && (!gout || ddl_aligned16(gout)) && (C % 4 == 0), DDL_EALIGN);
+extern "C" int ddl_bn_bwd_apply(const void* dz, const void* y, const void* z, const void* fcoef, const void* coef, void* dy,
+                                void* gout, long long M, int C, int mask, hipStream_t stream) {
+    CHK(dz && y && coef && dy && M > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
+    CHK(mask == 0 || (mask == 1 && z) || (mask == 2 && fcoef), DDL_EINVAL);
+    CHK(ddl_aligned16(dz) && ddl_aligned16(y) && ddl_aligned16(dy) && ddl_aligned16(coef) && (!z || ddl_aligned16(z)) &&
+        (!gout || ddl_aligned16(gout)) && (!fcoef || ddl_aligned16(fcoef)), DDL_EALIGN);
     long long nchunks = M * (C >> 3);
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
-#define L(R, G) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, G>), grid, block, 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
-    if (relu) { if (gout) L(true, true); else L(true, false); }
-    else { if (gout) L(false, true); else L(false, false); }
+#define L(MK, G) hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, G>), grid, block, 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
+    if (mask == 1) { if (gout) L(1, true); else L(1, false); }
+    else if (mask == 2) { if (gout) L(2, true); else L(2, false); }
+    else { if (gout) L(0, true); else L(0, false); }
 #undef L
     return ddl_launch_status();
 }

@@ -269,7 +269,7 @@ def _bn_fwd(y, gamma, beta, residual, stats, rmean, rvar, training, momentum, ep
     return z, coeffs
 
 
-def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None):
+def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True):
     """(dy, dgamma, dbeta, g) with g = dz masked by the ReLU (None unless want_g and relu).
 
     With ``beta`` given and direct gradients enabled, dgamma/dbeta are accumulated by the
@@ -279,7 +279,11 @@ def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None):
     dev = y.device
     G = K.bn_bwd_blocks(M)
     partial = torch.empty((G, 2, C), dtype=torch.float32, device=dev)
-    K.bn_bwd_reduce(dz, y, z, partial, M, C, relu, G)
+    # ReLU mask: from the stored activation when a residual was added before the ReLU, else
+    # recomputed from y with the forward scale/shift (z is then never read)
+    mask = 0 if not relu else (1 if has_res else 2)
+    fco = coeffs[2:4] if mask == 2 else None
+    K.bn_bwd_reduce(dz, y, z if mask == 1 else None, fco, partial, M, C, mask, G)
     coef = torch.empty((3, C), dtype=torch.float32, device=dev)
     direct = beta is not None and _DIRECT["on"] and _direct_grad_ok(gamma) and \
         _direct_grad_ok(beta) and gamma.grad.dtype == torch.float32 and \
@@ -294,7 +298,7 @@ def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None):
         dg, db = dgb[0], dgb[1]
     dy = torch.empty_like(y)
     g = torch.empty_like(y) if (want_g and relu) else None
-    K.bn_bwd_apply(dz, y, z, coef, dy, g, M, C, relu)
+    K.bn_bwd_apply(dz, y, z if mask == 1 else None, fco, coef, dy, g, M, C, mask)
     if want_g and not relu:
         g = dz
     if direct:
@@ -432,7 +436,7 @@ class BatchNormActFn(Function):
         y, z, gamma, coeffs = ctx.saved_tensors
         dz = _as_nhwc(dz)
         want_res = ctx.has_res and ctx.needs_input_grad[3]
-        dy, dg, db, gres = _bn_bwd(dz, y, z, gamma, coeffs, ctx.relu, want_res)
+        dy, dg, db, gres = _bn_bwd(dz, y, z, gamma, coeffs, ctx.relu, want_res, has_res=ctx.has_res)
         return dy, dg, db, gres, None, None, None, None, None, None, None
 
 
@@ -517,7 +521,8 @@ class ResidualBlockFn(Function):
         for i in range(units - 1, -1, -1):
             w, gam, bet = groups[i][0], groups[i][1], groups[i][2]
             last = i == units - 1
-            dy, dg, db, g = _bn_bwd(dz, ys[i], zs[i], gam, cs[i], True, last, beta=bet)
+            dy, dg, db, g = _bn_bwd(dz, ys[i], zs[i], gam, cs[i], True, last, beta=bet,
+                                    has_res=last)
             if last:
                 g_short = g
             inp = zs[i - 1] if i > 0 else x

@@ -219,9 +219,9 @@ def bn_bwd_blocks(M):
     return int(lib().ddl_bn_bwd_blocks(_i64(M)))
 
 
-def bn_bwd_reduce(dz, y, z, partial, M, C, relu, G):
-    check(lib().ddl_bn_bwd_reduce(ptr(dz), ptr(y), ptr(z), ptr(partial), _i64(M), _i32(C),
-                                  _i32(bool(relu)), _i32(G), stream()), "bn_bwd_reduce")
+def bn_bwd_reduce(dz, y, z, fcoef, partial, M, C, mask, G):
+    check(lib().ddl_bn_bwd_reduce(ptr(dz), ptr(y), ptr(z), ptr(fcoef), ptr(partial), _i64(M), _i32(C),
+                                  _i32(mask), _i32(G), stream()), "bn_bwd_reduce")
 
 
 def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef, accumulate=False):
@@ -230,9 +230,9 @@ def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef, 
                                     _i32(bool(accumulate)), stream()), "bn_bwd_finalize")
 
 
-def bn_bwd_apply(dz, y, z, coef, dy, gout, M, C, relu):
-    check(lib().ddl_bn_bwd_apply(ptr(dz), ptr(y), ptr(z), ptr(coef), ptr(dy), ptr(gout), _i64(M),
-                                 _i32(C), _i32(bool(relu)), stream()), "bn_bwd_apply")
+def bn_bwd_apply(dz, y, z, fcoef, coef, dy, gout, M, C, mask):
+    check(lib().ddl_bn_bwd_apply(ptr(dz), ptr(y), ptr(z), ptr(fcoef), ptr(coef), ptr(dy), ptr(gout),
+                                 _i64(M), _i32(C), _i32(mask), stream()), "bn_bwd_apply")
 
 
 def maxpool_fwd(x, out, idx, B, H, W, C):
