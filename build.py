@@ -87,8 +87,9 @@ def build_engine(force=False, jobs=8, verbose=True):
         return None
     os.makedirs(os.path.join(BUILD, "engine"), exist_ok=True)
     cxx = shutil.which("g++") or shutil.which("c++")
-    flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread",
-             "-I", os.path.join(ROOT, "csrc", "engine")]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread", "-D__HIP_PLATFORM_AMD__",
+             "-I", os.path.join(ROOT, "csrc", "engine"), "-I", os.path.join(rocm, "include")]
     todo, objs = [], []
     for s in srcs:
         o = os.path.join(BUILD, "engine", os.path.basename(s) + ".o")
@@ -106,7 +107,9 @@ def build_engine(force=False, jobs=8, verbose=True):
             if verbose:
                 print("[build] compiled", os.path.relpath(s, ROOT), flush=True)
     if todo or force or _newer(out, objs):
-        _run([cxx, "-shared", "-fPIC", "-pthread", "-o", out] + objs)
+        _run([cxx, "-shared", "-fPIC", "-pthread", "-o", out] + objs +
+             ["-L" + os.path.join(rocm, "lib"), "-Wl,-rpath," + os.path.join(rocm, "lib"),
+              "-lamdhip64", "-lrccl"])
         if verbose:
             print("[build] linked", os.path.relpath(out, ROOT), flush=True)
     return out

@@ -23,7 +23,7 @@ from ..utils.config import EngineConfig
 
 __all__ = ["init", "shutdown", "is_initialized", "rank", "size", "local_rank", "local_size",
            "cross_rank", "cross_size", "backend_name", "device", "group", "barrier",
-           "engine_config", "NotInitializedError", "supports_avg"]
+           "engine_config", "NotInitializedError", "supports_avg", "comm", "engine_name"]
 
 
 class NotInitializedError(ValueError):
@@ -40,6 +40,8 @@ class _State:
         self.local_size = 1
         self.backend = "single"
         self.group = None
+        self.comm = None
+        self.engine = "torch"
         self.owns_default_group = False
         self.config = EngineConfig()
         self.lock = threading.Lock()
@@ -93,7 +95,20 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
             # Pin the device before the communicator exists: RCCL binds to the current device.
             torch.cuda.set_device(_S.local_rank % n_dev)
 
-        if world > 1:
+        engine = (cfg.engine or "torch").lower()
+        if engine not in ("torch", "native"):
+            raise ValueError("unknown HVD_ENGINE %r (expected torch|native)" % engine)
+        _S.engine = engine
+        if world > 1 and engine == "native":
+            from .comm import NativeComm
+
+            _S.comm = NativeComm(rk, world, _S.local_rank,
+                                 os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                 int(os.environ.get("MASTER_PORT", "29500")),
+                                 timeout_s or cfg.collective_timeout_s, cfg.stall_warning_s,
+                                 use_rccl=(want == "rccl"), timeline=cfg.timeline)
+            _S.backend = want
+        elif world > 1:
             if dist.is_initialized():
                 _S.group = dist.group.WORLD
                 _S.owns_default_group = False
@@ -112,6 +127,9 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
                 _S.group = dist.group.WORLD
                 _S.owns_default_group = True
             _S.backend = want
+            from .comm import TorchComm
+
+            _S.comm = TorchComm(want, _S.group)
         else:
             _S.backend = "single"
         _S.initialized = True
@@ -121,6 +139,11 @@ def shutdown() -> None:
     with _S.lock:
         if not _S.initialized:
             return
+        if _S.comm is not None and _S.engine == "native":
+            try:
+                _S.comm.shutdown()
+            except Exception:  # pragma: no cover - teardown best effort
+                pass
         if _S.size > 1 and _S.owns_default_group and dist.is_initialized():
             try:
                 dist.destroy_process_group()
@@ -175,8 +198,18 @@ def backend_name() -> str:
 
 
 def supports_avg() -> bool:
-    """RCCL fuses the 1/size scaling into the reduction (ncclAvg); gloo does not."""
-    return _S.backend == "rccl"
+    """RCCL fuses the 1/size scaling into the reduction (ncclAvg) and so does the native engine;
+    gloo does not."""
+    return _S.comm.supports_avg if _S.comm is not None else _S.backend == "rccl"
+
+
+def comm():
+    """The active communication back-end (``parallel.comm``); None for single-process jobs."""
+    return _S.comm
+
+
+def engine_name() -> str:
+    return _S.engine
 
 
 def device() -> torch.device:
@@ -199,7 +232,4 @@ def engine_config() -> EngineConfig:
 def barrier() -> None:
     _require()
     if _S.size > 1:
-        if _S.backend == "rccl":
-            dist.barrier(group=_S.group, device_ids=[torch.cuda.current_device()])
-        else:
-            dist.barrier(group=_S.group)
+        _S.comm.barrier()

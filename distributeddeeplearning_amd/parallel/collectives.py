@@ -80,12 +80,12 @@ def _resolve_op(average, op):
 
 def _check_consistency(kind, tensor, name):
     """Debug-mode guard: all ranks must submit the same (kind, name, shape, dtype)."""
-    if not _b.engine_config().debug or _b.size() == 1:
+    if not _b.engine_config().debug or _b.size() == 1 or _b.comm().checks_consistency:
         return
     sig = "%s|%s|%s|%s" % (kind, name, tuple(tensor.shape), tensor.dtype)
     digest = int.from_bytes(hashlib.sha1(sig.encode()).digest()[:6], "big")
     probe = torch.tensor([digest, -digest], dtype=torch.int64, device=_b.device())
-    dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=_b.group())
+    _b.comm().all_reduce(probe, Max, name="consistency").wait()
     hi, neg_lo = probe.tolist()
     if hi != digest or -neg_lo != digest:
         raise HandleError("collective mismatch across ranks for %s (this rank: %s)" % (name, sig))
@@ -95,19 +95,20 @@ def _staged(tensor):
     """Tensor as the active backend can move it: gloo cannot touch device memory, so a GPU
     tensor under the gloo backend is staged through the host (multi-rank-on-one-GPU
     tests)."""
-    if _b.backend_name() == "gloo" and tensor.is_cuda:
+    host_only = _b.backend_name() == "gloo"
+    if host_only and tensor.is_cuda:
         return tensor.detach().cpu(), True
     return tensor, False
 
 
-def _launch_allreduce(buf, op):
+def _launch_allreduce(buf, op, name=None):
     """Enqueue the reduction of ``buf`` in place; returns (work, needs_scale)."""
+    c = _b.comm()
     if op == Average:
-        if _b.supports_avg() and buf.is_floating_point():
-            return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=_b.group(), async_op=True), False
-        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_b.group(), async_op=True), True
-    red = {Sum: dist.ReduceOp.SUM, Min: dist.ReduceOp.MIN, Max: dist.ReduceOp.MAX}[op]
-    return dist.all_reduce(buf, op=red, group=_b.group(), async_op=True), False
+        if c.supports_avg and buf.is_floating_point():
+            return c.all_reduce(buf, Average, name), False
+        return c.all_reduce(buf, Sum, name), True
+    return c.all_reduce(buf, op, name), False
 
 
 def _scale_inplace(t, world):
@@ -131,7 +132,7 @@ def allreduce_async_(tensor, average=None, name=None, op=None, compression=Compr
     if not buf.is_contiguous():
         buf = buf.contiguous()
         staged = True
-    work, needs_scale = _launch_allreduce(buf, op)
+    work, needs_scale = _launch_allreduce(buf, op, name)
 
     def finish():
         if needs_scale:
@@ -189,16 +190,17 @@ def allgather_async(tensor, name=None):
     src, _ = _staged(tensor.detach().contiguous())
     dev = src.device
     first = torch.tensor([src.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(first) for _ in range(world)]
-    dist.all_gather(counts, first, group=_b.group())
-    counts = [int(c.item()) for c in counts]
+    counts_t = torch.zeros((world, 1), dtype=torch.int64, device=dev)
+    _b.comm().all_gather_into(counts_t, first, name=name + ".counts").wait()
+    counts = [int(c) for c in counts_t.view(-1).tolist()]
     longest = max(counts)
     padded = src
     if src.shape[0] != longest:
         padded = src.new_zeros((longest,) + tuple(src.shape[1:]))
         padded[: src.shape[0]].copy_(src)
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    work = dist.all_gather(parts, padded, group=_b.group(), async_op=True)
+    gathered = torch.empty((world,) + tuple(padded.shape), dtype=padded.dtype, device=dev)
+    parts = list(gathered.unbind(0))
+    work = _b.comm().all_gather_into(gathered, padded.contiguous(), name=name)
     holder = {}
 
     def finish():
@@ -225,7 +227,7 @@ def broadcast_async_(tensor, root_rank, name=None):
     buf, staged = _staged(tensor)
     if not buf.is_contiguous():
         buf, staged = buf.contiguous(), True
-    work = dist.broadcast(buf, src=root_rank, group=_b.group(), async_op=True)
+    work = _b.comm().broadcast(buf, root_rank, name)
 
     def finish():
         if staged:
@@ -261,7 +263,8 @@ def synchronize(handle):
     if pending is None:
         raise HandleError("unknown or already synchronised handle %r" % (handle,))
     if pending.work is not None:
-        pending.work.wait()
+        if not pending.work.wait(_b.engine_config().collective_timeout_s):
+            raise HandleError("collective %s timed out" % (pending.name,))
     if pending.finish is not None:
         return pending.finish()
     return pending.result
@@ -280,17 +283,10 @@ def broadcast_object(obj, root_rank=0, name=None):
     """Broadcast an arbitrary picklable object through the control plane."""
     if _b.size() == 1:
         return obj
-    box = [obj if _b.rank() == root_rank else None]
-    kwargs = {}
-    if _b.backend_name() == "rccl":
-        kwargs["device"] = _b.device()
-    dist.broadcast_object_list(box, src=root_rank, group=_b.group(), **kwargs)
-    return box[0]
+    return _b.comm().broadcast_object(obj, root_rank, _b.rank())
 
 
 def allgather_object(obj, name=None):
     if _b.size() == 1:
         return [obj]
-    out = [None] * _b.size()
-    dist.all_gather_object(out, obj, group=_b.group())
-    return out
+    return _b.comm().all_gather_object(obj, _b.size())

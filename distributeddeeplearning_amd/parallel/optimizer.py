@@ -109,7 +109,7 @@ class _DistributedMixin:
         text = self._ddl_arena.describe() + "|" + "|".join(sorted(self._ddl_names.values()))
         digest = int.from_bytes(hashlib.sha1(text.encode()).digest()[:6], "big")
         probe = torch.tensor([digest, -digest], dtype=torch.int64, device=_b.device())
-        dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=_b.group())
+        _b.comm().all_reduce(probe, "max", name="plan_hash").wait()
         hi, neg_lo = probe.tolist()
         if hi != digest or -neg_lo != digest:
             raise RuntimeError("gradient bucket plans differ across ranks")
@@ -142,23 +142,19 @@ class _DistributedMixin:
             wire = wire.cpu()
         st.wire, st.ctx = wire, ctx
         if _b.supports_avg():
-            st.work = dist.all_reduce(wire, op=dist.ReduceOp.AVG, group=_b.group(),
-                                      async_op=True)
+            st.work = _b.comm().all_reduce(wire, "average", name)
             st.needs_scale = False
         else:
-            st.work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=_b.group(),
-                                      async_op=True)
+            st.work = _b.comm().all_reduce(wire, "sum", name)
             st.needs_scale = True
 
     def _ddl_finish(self, st):
         if st.work is None:
             return
         deadline = _b.engine_config().collective_timeout_s
-        if _b.backend_name() == "gloo":
-            if not st.work.wait(timeout=_timedelta(deadline)):
-                raise RuntimeError("gradient allreduce timed out after %.0f s" % deadline)
-        else:
-            st.work.wait()  # stream-ordered: the host does not block
+        # device collectives are stream-ordered (the host does not block); host ones wait here
+        if not st.work.wait(deadline):
+            raise RuntimeError("gradient allreduce timed out after %.0f s" % deadline)
         wire = st.wire
         if st.needs_scale:
             wire.div_(_b.size())

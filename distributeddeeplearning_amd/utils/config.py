@@ -157,6 +157,7 @@ class EngineConfig:
     first_bucket_bytes: int = 8 * 1024 * 1024  # small first bucket: comm starts early in backward
     comm_dtype: str = "auto"  # auto = gradient dtype | bf16 | fp32
     backend: str = "auto"  # auto | rccl | gloo
+    engine: str = "torch"  # torch (c10d process group) | native (in-tree C++ engine)
     timeline: Optional[str] = None
     debug: bool = False
     collective_timeout_s: float = 300.0
@@ -172,6 +173,7 @@ class EngineConfig:
             first_bucket_bytes=env_int("HVD_FIRST_BUCKET_BYTES", 8 * 1024 * 1024),
             comm_dtype=env_str("HVD_COMM_DTYPE", "auto"),
             backend=env_str("HVD_BACKEND", "auto"),
+            engine=env_str("HVD_ENGINE", "torch"),
             timeline=env_str("HVD_TIMELINE", None, "HOROVOD_TIMELINE"),
             debug=env_bool("HVD_DEBUG", False),
             collective_timeout_s=env_float("HVD_COLLECTIVE_TIMEOUT_S", 300.0),

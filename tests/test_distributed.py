@@ -32,8 +32,9 @@ def _launch(scenario, np_total=2, exports=None, timeout=240):
     return rc, results, out
 
 
-def test_collectives_np2():
-    rc, res, out = _launch("collectives")
+@pytest.mark.parametrize("engine", ["torch", "native"])
+def test_collectives_np2(engine):
+    rc, res, out = _launch("collectives", exports={"HVD_ENGINE": engine})
     assert rc == 0, out
     assert set(res) == {0, 1}
     for r in (0, 1):
@@ -48,9 +49,10 @@ def test_collectives_np2():
     assert "[0]<localhost>" in out and "[1]<localhost>" in out  # per-rank output tagging
 
 
-@pytest.mark.parametrize("fused", ["0", "1"])
-def test_distributed_optimizer_equals_large_batch(fused):
-    rc, res, out = _launch("optimizer_equivalence", exports={"TEST_FUSED": fused})
+@pytest.mark.parametrize("fused,engine", [("0", "torch"), ("1", "torch"), ("1", "native")])
+def test_distributed_optimizer_equals_large_batch(fused, engine):
+    rc, res, out = _launch("optimizer_equivalence", exports={"TEST_FUSED": fused,
+                                                             "HVD_ENGINE": engine})
     assert rc == 0, out
     p0, p1 = torch.tensor(res[0]["params"]), torch.tensor(res[1]["params"])
     assert torch.equal(p0, p1)  # replicas stay identical
@@ -74,8 +76,10 @@ def test_distributed_optimizer_equals_large_batch(fused):
     assert "bucket 0" in res[0]["buckets"]
 
 
-def test_checkpoint_rank0_only_and_resume(tmp_path):
-    rc, res, out = _launch("checkpoint_resume", exports={"TEST_CKPT_DIR": str(tmp_path)})
+@pytest.mark.parametrize("engine", ["torch", "native"])
+def test_checkpoint_rank0_only_and_resume(tmp_path, engine):
+    rc, res, out = _launch("checkpoint_resume", exports={"TEST_CKPT_DIR": str(tmp_path),
+                                                         "HVD_ENGINE": engine})
     assert rc == 0, out
     assert res[0]["wrote"] is True and res[1]["wrote"] is False
     for r in (0, 1):
@@ -85,16 +89,18 @@ def test_checkpoint_rank0_only_and_resume(tmp_path):
     assert payload["epoch"] == 3 and "0.weight" in payload["model"] and "optimizer" in payload
 
 
-def test_rank_death_kills_job_not_hangs():
-    rc, res, out = _launch("fault", exports={"HVD_FAULT_INJECT": "1:2",
+@pytest.mark.parametrize("engine", ["torch", "native"])
+def test_rank_death_kills_job_not_hangs(engine):
+    rc, res, out = _launch("fault", exports={"HVD_FAULT_INJECT": "1:2", "HVD_ENGINE": engine,
                                              "HVD_COLLECTIVE_TIMEOUT_S": "20"}, timeout=120)
     assert rc != 0
     assert "terminating the job" in out
     assert 1 not in res
 
 
-def test_debug_mode_detects_shape_mismatch():
-    rc, res, out = _launch("mismatch", timeout=120)
+@pytest.mark.parametrize("engine", ["torch", "native"])
+def test_debug_mode_detects_shape_mismatch(engine):
+    rc, res, out = _launch("mismatch", exports={"HVD_ENGINE": engine}, timeout=120)
     assert res and all(r["raised"] for r in res.values()), out
 
 
@@ -135,3 +141,17 @@ def test_resnet50_gloo_np2_batch4_example():
     assert "Total images/sec:" in out and "Num GPUs:         2.000" in out
     assert "Batch size:       (Per GPU 4: Total 8)" in out
     assert out.count("Runnin Distributed") == 2
+
+
+def test_native_engine_np4_and_timeline(tmp_path):
+    """Ring collectives at 4 ranks (uneven chunking) + the engine-written chrome trace."""
+    rc, res, out = _launch("collectives", np_total=4,
+                           exports={"HVD_ENGINE": "native", "HVD_TIMELINE": str(tmp_path / "tl")})
+    assert rc == 0, out
+    assert set(res) == {0, 1, 2, 3}
+    for r in range(4):
+        assert res[r]["avg"] == [2.5] * 5 and res[r]["sum"] == [10.0] * 5
+        assert res[r]["gather"] == [0.0] * 2 + [1.0] * 4 + [2.0] * 6 + [3.0] * 8
+    trace = json.loads((tmp_path / "tl.engine.0.json").read_text())
+    names = {e["name"] for e in trace}
+    assert "t.avg" in names and any(e.get("ph") == "B" for e in trace)

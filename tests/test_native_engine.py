@@ -1,0 +1,102 @@
+"""In-process tests of the C++ engine pieces: bucket planner twin and size-1 engine plumbing."""
+import ctypes
+import socket
+
+import pytest
+import torch
+
+from distributeddeeplearning_amd.ops import native
+from distributeddeeplearning_amd.parallel.bucket import (BUCKET_ALIGN_BYTES, SEG_ALIGN_BYTES,
+                                                         plan_arenas)
+
+lib = native.engine_lib()
+pytestmark = pytest.mark.skipif(lib is None, reason="engine library not built")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_native_bucket_plan_matches_python_planner():
+    from distributeddeeplearning_amd.models import resnet50
+
+    m = resnet50()
+    entries = [(n, p.shape, torch.float32) for n, p in m.named_parameters()]
+    plan = plan_arenas(entries, 8 << 20, 32 << 20)[torch.float32]
+    numel = [s.numel for s in plan.segments]  # planning (reverse) order
+    n = len(numel)
+    arr = (ctypes.c_longlong * n)(*numel)
+    offsets = (ctypes.c_longlong * n)()
+    bucket = (ctypes.c_int * n)()
+    bucket_end = (ctypes.c_longlong * n)()
+    arena = ctypes.c_longlong(0)
+    nb = lib.ddl_bucket_plan(arr, n, 4, ctypes.c_longlong(8 << 20), ctypes.c_longlong(32 << 20),
+                             SEG_ALIGN_BYTES, BUCKET_ALIGN_BYTES, offsets, bucket, bucket_end,
+                             ctypes.byref(arena))
+    assert nb == len(plan.buckets) and arena.value == plan.numel
+    assert list(offsets) == [s.offset for s in plan.segments]
+    assert [bucket_end[i] for i in range(nb)] == [b.end for b in plan.buckets]
+    seg_bucket = {}
+    for b in plan.buckets:
+        for s in b.segments:
+            seg_bucket[s.name] = b.index
+    assert list(bucket) == [seg_bucket[s.name] for s in plan.segments]
+
+
+def test_engine_single_rank_store_and_handles(tmp_path):
+    lib.ddl_eng_last_error.restype = ctypes.c_char_p
+    lib.ddl_eng_store_data.restype = ctypes.c_void_p
+    for fn in ("ddl_eng_allreduce_async", "ddl_eng_allgather_async", "ddl_eng_store_get",
+               "ddl_eng_store_add"):
+        getattr(lib, fn).restype = ctypes.c_longlong
+    port = _free_port()
+    assert lib.ddl_eng_init(0, 1, b"127.0.0.1", port, ctypes.c_double(10.0), ctypes.c_double(5.0)) == 0
+    try:
+        assert lib.ddl_eng_rank() == 0 and lib.ddl_eng_size() == 1
+        assert lib.ddl_eng_timeline_start(str(tmp_path / "t.json").encode()) == 0
+        t = torch.arange(8, dtype=torch.float32)
+        h = lib.ddl_eng_allreduce_async(ctypes.c_void_p(t.data_ptr()), ctypes.c_longlong(8), 0, 1, b"x")
+        assert lib.ddl_eng_wait(ctypes.c_longlong(h), ctypes.c_double(5.0)) == 0
+        assert t.tolist() == list(range(8))
+        assert lib.ddl_eng_wait(ctypes.c_longlong(h), ctypes.c_double(0.1)) == -1  # consumed
+        assert lib.ddl_eng_store_set(b"k", b"hello", ctypes.c_longlong(5)) == 0
+        n = lib.ddl_eng_store_get(b"k", 1000)
+        assert ctypes.string_at(lib.ddl_eng_store_data(), n) == b"hello"
+        assert lib.ddl_eng_store_get(b"missing", 100) == -1  # blocking get times out
+        assert lib.ddl_eng_store_add(b"ctr", ctypes.c_longlong(3)) == 3
+        assert lib.ddl_eng_store_add(b"ctr", ctypes.c_longlong(4)) == 7
+        lib.ddl_eng_timeline_stop()
+        assert "ENQUEUE" in (tmp_path / "t.json").read_text()
+    finally:
+        lib.ddl_eng_shutdown()
+
+
+@pytest.mark.gpu
+def test_rccl_backend_single_gpu_event_plumbing():
+    """The direct RCCL data plane on one MI355X (communicator of size 1): stream-ordered
+    all-reduce / broadcast through event hand-offs, no host synchronisation."""
+    for fn in ("ddl_rccl_allreduce", "ddl_rccl_broadcast"):
+        getattr(lib, fn).restype = ctypes.c_longlong
+    lib.ddl_rccl_last_error.restype = ctypes.c_char_p
+    port = _free_port()
+    assert lib.ddl_eng_init(0, 1, b"127.0.0.1", port, ctypes.c_double(30.0), ctypes.c_double(10.0)) == 0
+    try:
+        assert lib.ddl_rccl_init(0, 1, torch.cuda.current_device(), 30000) == 0, lib.ddl_rccl_last_error()
+        x = torch.randn(1 << 20, device="cuda").to(torch.bfloat16)
+        ref = (x.float() * 2).to(torch.bfloat16)
+        y = x * 2  # producer kernel on the torch stream; the collective must wait for it
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        h = lib.ddl_rccl_allreduce(ctypes.c_void_p(y.data_ptr()), ctypes.c_longlong(y.numel()), 3, 1, s, b"g")
+        assert h > 0, lib.ddl_rccl_last_error()
+        assert lib.ddl_rccl_wait_stream(ctypes.c_longlong(h), s) == 0
+        z = y + 0  # consumer ordered after the collective
+        torch.cuda.synchronize()
+        assert torch.equal(z, ref)
+        h = lib.ddl_rccl_broadcast(ctypes.c_void_p(y.data_ptr()), ctypes.c_longlong(y.numel()), 3, 0, s, b"b")
+        assert lib.ddl_rccl_wait_host(ctypes.c_longlong(h)) == 0
+        assert lib.ddl_rccl_poll(ctypes.c_longlong(h)) == -1
+    finally:
+        lib.ddl_rccl_shutdown()
+        lib.ddl_eng_shutdown()
