@@ -1,0 +1,204 @@
+// K18 / K17: direct-access all-reduce over peer-mapped buffers, and multi-tensor pack/unpack.
+//
+// xGMI on an 8-GPU MI355X node is a full mesh of point-to-point links (7 x ~153 GB/s per GPU).
+// A ring uses one link per GPU; the two-shot direct algorithm uses all seven at once
+// (SURVEY §5.8): rank r owns shard r of the bucket;
+//   phase 1  r reads shard r from every peer's buffer (7 links in, concurrently), reduces in fp32;
+//   phase 2  r writes the reduced (and averaged) shard into every peer's buffer (7 links out).
+// Per-link traffic is 2 x S/8 instead of the ring's 2 x 7/8 S.  One-shot (every rank reads every
+// buffer whole and keeps the sum) serves latency-bound buckets.
+//
+// Synchronisation is by epoch-stamped flags in each rank's own flag page (peers push, the owner
+// polls locally): system-scope release before every flag store, system-scope acquire after every
+// successful poll.  Every spin is bounded; on expiry the kernel raises `timeout_word` and
+// returns (the host turns that into an error) — it can never hang the device.  The grid is
+// small (default 16 workgroups) so it can overlap with backward convolutions without starving
+// them, and every workgroup of the grid is resident by construction (16 << 256 CUs).
+//
+// Status: protocol and indexing are validated on one device with several simulated ranks
+// (tests/test_gpu_kernels.py); on real multi-GPU hardware peer visibility additionally depends
+// on the peer mapping being fine-grained — the algorithm is therefore opt-in
+// (HVD_ALLREDUCE_ALGO=twoshot) and RCCL stays the default data plane.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_RANKS = 8;
+
+struct XgmiParams {
+    void* bufs[MAX_RANKS];        // peer-mapped data buffers (index = rank)
+    unsigned* flags[MAX_RANKS];   // peer-mapped flag pages: [0..7] ready, [8..15] done, [16] block ticket
+    void* outs[MAX_RANKS];        // one-shot: output buffer of each rank (only [rank] is used outside simulation)
+    int simulate;                 // test mode: ONE launch plays every rank, rank = blockIdx.y
+    long long count;              // elements, multiple of 8 * nranks
+    int rank, nranks, is_bf16, one_shot;
+    unsigned epoch;               // > 0, strictly increasing per call
+    float scale;                  // 1/nranks for averaging, 1 for sum
+    long long spin_limit;
+    unsigned* timeout_word;
+};
+
+__device__ __forceinline__ bool wait_flag(unsigned* p, unsigned epoch, long long limit) {
+    for (long long i = 0; i < limit; ++i) {
+        unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)(v - epoch) >= 0) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+
+template <bool BF16>
+__device__ __forceinline__ void load8(const void* base, long long i8, float* v) {
+    if (BF16) {
+        bf16x8 x = *reinterpret_cast<const bf16x8*>((const bf16_t*)base + i8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(x[e]);
+    } else {
+        f32x4 a = *reinterpret_cast<const f32x4*>((const float*)base + i8 * 8);
+        f32x4 b = *reinterpret_cast<const f32x4*>((const float*)base + i8 * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ void store8(void* base, long long i8, const float* v) {
+    if (BF16) {
+        bf16x8 x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x8*>((bf16_t*)base + i8 * 8) = x;
+    } else {
+        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>((float*)base + i8 * 8) = a;
+        *reinterpret_cast<f32x4*>((float*)base + i8 * 8 + 4) = b;
+    }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256) xgmi_allreduce_kernel(const XgmiParams p) {
+    __shared__ int ok_s;
+    const int n = p.nranks;
+    const int r = p.simulate ? (int)blockIdx.y : p.rank;
+    // 1. announce "my buffer holds this step's input" to every rank (including myself)
+    if (blockIdx.x == 0 && threadIdx.x < n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope
+        __hip_atomic_store(p.flags[threadIdx.x] + r, p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 2. wait until every rank has announced (poll my own flag page)
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        for (int q = 0; q < n && ok; ++q) ok = wait_flag(p.flags[r] + q, p.epoch, p.spin_limit);
+        if (!ok) __hip_atomic_store(p.timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        ok_s = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!ok_s) return;  // uniform per block; peers time out on their own bounded spins
+
+    const long long total8 = p.count >> 3;
+    const long long shard8 = p.one_shot ? total8 : total8 / n;
+    const long long base8 = p.one_shot ? 0 : shard8 * r;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < shard8; i += stride) {
+        float acc[8], v[8];
+        load8<BF16>(p.bufs[0], base8 + i, acc);
+        for (int q = 1; q < n; ++q) {
+            load8<BF16>(p.bufs[q], base8 + i, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= p.scale;
+        if (p.one_shot) {
+            store8<BF16>(p.outs[r], i, acc);
+        } else {
+            for (int q = 0; q < n; ++q) store8<BF16>(p.bufs[(r + q) % n], base8 + i, acc);
+        }
+    }
+    // 3. publish: every writing wave drains its stores, the last workgroup signals "done"
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* ticket = p.flags[r] + 16;
+        unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        ok_s = (t == gridDim.x - 1) ? 1 : 0;
+        if (ok_s) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!ok_s) return;
+    if (threadIdx.x < n)
+        __hip_atomic_store(p.flags[threadIdx.x] + 8 + r, p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // 4. the kernel may only complete once every rank's writes into MY buffer have landed
+    //    (two-shot) / every rank has finished reading my buffer (one-shot)
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        for (int q = 0; q < n && ok; ++q) ok = wait_flag(p.flags[r] + 8 + q, p.epoch, p.spin_limit);
+        if (!ok) __hip_atomic_store(p.timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+}
+
+// ---- K17: multi-tensor pack (gather, scale, cast) and unpack ---------------------------------
+struct PackEntry { long long src; long long dst; long long numel; };  // byte address, element offset, elements
+
+template <typename SrcT, typename DstT, bool UNPACK>
+__global__ void __launch_bounds__(256) pack_kernel(const PackEntry* __restrict__ table, int nentries, void* flat, float scale) {
+    for (int k = blockIdx.y; k < nentries; k += gridDim.y) {
+        const PackEntry e = table[k];
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < e.numel; i += stride) {
+            if (UNPACK) {
+                float v = (float)((const DstT*)flat)[e.dst + i] * scale;
+                ((SrcT*)e.src)[i] = (SrcT)v;
+            } else {
+                float v = (float)((const SrcT*)e.src)[i] * scale;
+                ((DstT*)flat)[e.dst + i] = (DstT)v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ddl_xgmi_allreduce(void* const* bufs, void* const* flags, void* const* outs, long long count, int rank, int nranks,
+                                  int is_bf16, int one_shot, unsigned epoch, float scale, long long spin_limit,
+                                  void* timeout_word, int blocks, int simulate, hipStream_t stream) {
+    if (!bufs || !flags || !timeout_word || nranks < 1 || nranks > MAX_RANKS || rank < 0 || rank >= nranks) return DDL_EINVAL;
+    if (count <= 0 || (count % (8LL * nranks)) != 0 || epoch == 0 || spin_limit <= 0) return DDL_EINVAL;
+    if (one_shot && !outs) return DDL_EINVAL;
+    if (blocks < 1 || blocks > 64) return DDL_EINVAL;  // small by design: always fully resident
+    XgmiParams p;
+    for (int i = 0; i < MAX_RANKS; ++i) { p.bufs[i] = nullptr; p.flags[i] = nullptr; p.outs[i] = nullptr; }
+    for (int i = 0; i < nranks; ++i) {
+        if (!bufs[i] || !flags[i] || !ddl_aligned16(bufs[i])) return DDL_EALIGN;
+        p.bufs[i] = bufs[i]; p.flags[i] = (unsigned*)flags[i];
+        if (one_shot && (simulate || i == rank)) {
+            if (!outs[i] || !ddl_aligned16(outs[i])) return DDL_EALIGN;
+            p.outs[i] = outs[i];
+        }
+    }
+    p.simulate = simulate; p.count = count; p.rank = rank; p.nranks = nranks; p.is_bf16 = is_bf16; p.one_shot = one_shot;
+    p.epoch = epoch; p.scale = scale; p.spin_limit = spin_limit; p.timeout_word = (unsigned*)timeout_word;
+    if (is_bf16) hipLaunchKernelGGL(xgmi_allreduce_kernel<true>, dim3(blocks, simulate ? nranks : 1), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(xgmi_allreduce_kernel<false>, dim3(blocks, simulate ? nranks : 1), dim3(256), 0, stream, p);
+    return ddl_launch_status();
+}
+
+// table: device array of {src byte address, dst element offset, numel}; src dtype fp32 or bf16,
+// flat dtype fp32 or bf16; unpack writes flat*scale back into the sources.
+extern "C" int ddl_pack_scale_cast(const void* table, int nentries, void* flat, int src_is_bf16, int flat_is_bf16,
+                                   float scale, int unpack, hipStream_t stream) {
+    if (!table || !flat || nentries <= 0) return DDL_EINVAL;
+    dim3 grid(64, nentries < 256 ? nentries : 256), block(256);
+#define PK(S, D, U) hipLaunchKernelGGL((pack_kernel<S, D, U>), grid, block, 0, stream, (const PackEntry*)table, nentries, flat, scale)
+    if (src_is_bf16) {
+        if (flat_is_bf16) { if (unpack) PK(bf16_t, bf16_t, true); else PK(bf16_t, bf16_t, false); }
+        else { if (unpack) PK(bf16_t, float, true); else PK(bf16_t, float, false); }
+    } else {
+        if (flat_is_bf16) { if (unpack) PK(float, bf16_t, true); else PK(float, bf16_t, false); }
+        else { if (unpack) PK(float, float, true); else PK(float, float, false); }
+    }
+#undef PK
+    return ddl_launch_status();
+}

@@ -278,3 +278,34 @@ def stem_pack(x, out):
     sb, sc, sh, sw = x.stride()
     check(lib().ddl_stem_pack(ptr(x), ptr(out), _i32(B), _i32(H), _i32(W), _i32(C), _i64(sb), _i64(sh),
                               _i64(sw), _i64(sc), stream()), "stem_pack")
+
+
+# ---- direct xGMI all-reduce and multi-tensor pack (csrc/kernels/xgmi_allreduce.hip) ----------
+def xgmi_allreduce(buf_ptrs, flag_ptrs, out_ptrs, count, rank, nranks, is_bf16, one_shot, epoch,
+                   scale, timeout_word, blocks=16, spin_limit=2_000_000, simulate=False):
+    """Raw launcher: ``buf_ptrs`` / ``flag_ptrs`` / ``out_ptrs`` are lists of device addresses
+    indexed by rank (``out_ptrs`` only for one-shot).  ``simulate`` plays every rank in one
+    launch (single-device protocol test)."""
+    arr = ctypes.c_void_p * nranks
+    outs = arr(*[o or 0 for o in out_ptrs]) if out_ptrs else None
+    check(lib().ddl_xgmi_allreduce(arr(*buf_ptrs), arr(*flag_ptrs), outs, _i64(count),
+                                   _i32(rank), _i32(nranks), _i32(bool(is_bf16)),
+                                   _i32(bool(one_shot)), ctypes.c_uint(epoch), _f32(scale),
+                                   _i64(spin_limit), ptr(timeout_word), _i32(blocks),
+                                   _i32(bool(simulate)), stream()), "xgmi_allreduce")
+
+
+def pack_scale_cast(tensors, flat, offsets, scale=1.0, unpack=False):
+    """K17: gather ``tensors`` (all fp32 or all bf16, contiguous) into ``flat`` at element
+    ``offsets`` with scaling and dtype cast — or scatter back when ``unpack``."""
+    import numpy as np
+
+    src_dt = tensors[0].dtype
+    assert all(t.dtype == src_dt and t.is_contiguous() for t in tensors)
+    tab = np.array([(t.data_ptr(), o, t.numel()) for t, o in zip(tensors, offsets)], dtype=np.int64)
+    table = torch.from_numpy(tab).to(flat.device)
+    check(lib().ddl_pack_scale_cast(ptr(table), _i32(len(tensors)), ptr(flat),
+                                    _i32(src_dt == torch.bfloat16),
+                                    _i32(flat.dtype == torch.bfloat16), _f32(scale),
+                                    _i32(bool(unpack)), stream()), "pack_scale_cast")
+    return table  # keep alive until the stream has consumed it

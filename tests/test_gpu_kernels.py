@@ -373,3 +373,55 @@ def test_philox_statistics():
     lab = torch.empty(1 << 16, dtype=torch.int64, device=DEV)
     kernels.philox_labels_(lab, 1000, 7)
     assert int(lab.min()) >= 0 and int(lab.max()) < 1000
+
+
+@pytest.mark.parametrize("one_shot", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n", [2, 8])
+def test_xgmi_allreduce_protocol_simulated_ranks(n, dtype, one_shot):
+    """K18 on one device: ``n`` simulated ranks (n buffers, n flag pages, one launch whose
+    blockIdx.y plays the rank, so all ranks are co-resident) run the two-shot / one-shot
+    protocol; uneven input magnitudes, every word checked; three epochs back to back exercise
+    flag and ticket reuse."""
+    from distributeddeeplearning_amd.ops import kernels
+
+    kernels.require()
+    count = 8 * n * 1237
+    bufs = [torch.empty(count, dtype=dtype, device=DEV) for _ in range(n)]
+    flags = [torch.zeros(32, dtype=torch.int32, device=DEV) for _ in range(n)]
+    outs = [torch.empty(count, dtype=dtype, device=DEV) for _ in range(n)]
+    tmo = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for epoch in (1, 2, 3):
+        src = [(torch.randn(count, device=DEV) * (r + 1) * epoch).to(dtype) for r in range(n)]
+        for r in range(n):
+            bufs[r].copy_(src[r])
+        expect = sum(t.float() for t in src) / n
+        kernels.xgmi_allreduce([b.data_ptr() for b in bufs], [f.data_ptr() for f in flags],
+                               [o.data_ptr() for o in outs] if one_shot else None, count, 0, n,
+                               dtype == torch.bfloat16, one_shot, epoch, 1.0 / n, tmo, blocks=8,
+                               spin_limit=2_000_000, simulate=True)
+        torch.cuda.synchronize()
+        assert int(tmo.item()) == 0, "a simulated rank timed out"
+        tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+        for r in range(n):
+            got = (outs[r] if one_shot else bufs[r]).float()
+            assert torch.allclose(got, expect, rtol=tol, atol=tol * float(expect.abs().max())), (epoch, r)
+
+
+def test_pack_scale_cast_roundtrip():
+    from distributeddeeplearning_amd.ops import kernels
+
+    kernels.require()
+    ts = [torch.randn(n, device=DEV) for n in (5, 1000, 77)]
+    offs = [0, 8, 1016]
+    flat = torch.zeros(1100, dtype=BF, device=DEV)
+    keep = kernels.pack_scale_cast(ts, flat, offs, scale=0.5)
+    torch.cuda.synchronize()
+    for t, o in zip(ts, offs):
+        assert torch.allclose(flat[o:o + t.numel()].float(), t * 0.5, rtol=1e-2, atol=1e-2)
+    back = [torch.empty_like(t) for t in ts]
+    keep2 = kernels.pack_scale_cast(back, flat, offs, scale=2.0, unpack=True)
+    torch.cuda.synchronize()
+    for t, b in zip(ts, back):
+        assert torch.allclose(b, t, rtol=1e-2, atol=2e-2)
+    del keep, keep2
