@@ -1,0 +1,107 @@
+"""Deployment / data-preparation tooling (SURVEY C19-C22 counterparts)."""
+import io
+import json
+import os
+import sys
+import tarfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import create_resources  # noqa: E402
+import local_smoke  # noqa: E402
+import prepare_imagenet  # noqa: E402
+import submit_job  # noqa: E402
+
+
+def _tar_bytes(files):
+    buf = io.BytesIO()
+    with tarfile.open(fileobj=buf, mode="w") as t:
+        for name, data in files.items():
+            info = tarfile.TarInfo(name)
+            info.size = len(data)
+            t.addfile(info, io.BytesIO(data))
+    return buf.getvalue()
+
+
+def test_prepare_train_nested_tars(tmp_path):
+    outer = _tar_bytes({"n01.tar": _tar_bytes({"n01_1.JPEG": b"a", "n01_2.JPEG": b"b"}),
+                        "n02.tar": _tar_bytes({"n02_1.JPEG": b"c"})})
+    (tmp_path / "train.tar").write_bytes(outer)
+    assert prepare_imagenet.prepare_train(str(tmp_path / "train.tar"), str(tmp_path / "train")) == (2, 3)
+    assert sorted(os.listdir(tmp_path / "train" / "n01")) == ["n01_1.JPEG", "n01_2.JPEG"]
+
+
+def test_prepare_val_from_valprep_style_script(tmp_path):
+    (tmp_path / "valprep.sh").write_text(
+        "#!/usr/bin/env bash\nmkdir -p n01\nmkdir -p n02\nmv v1.JPEG n02/\nmv v2.JPEG n01/\n")
+    flat = tmp_path / "flat"
+    flat.mkdir()
+    (flat / "v1.JPEG").write_bytes(b"x")
+    (flat / "v2.JPEG").write_bytes(b"y")
+    mapping, classes = prepare_imagenet.parse_mapping(str(tmp_path / "valprep.sh"))
+    assert mapping == {"v1.JPEG": "n02", "v2.JPEG": "n01"} and classes == ["n01", "n02"]
+    assert prepare_imagenet.prepare_val(str(flat), str(tmp_path / "val"), str(tmp_path / "valprep.sh")) == (2, 2, 0)
+    assert os.path.isfile(tmp_path / "val" / "n02" / "v1.JPEG")
+    arch = prepare_imagenet.pack(str(tmp_path / "val"), str(tmp_path / "val.tar.gz"))
+    assert tarfile.is_tarfile(arch)
+
+
+def test_reference_valprep_is_parseable_as_data():
+    ref = "/root/reference/valprep.sh"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not mounted")
+    mapping, classes = prepare_imagenet.parse_mapping(ref)
+    assert len(classes) == 1000 and len(mapping) == 50000
+
+
+def test_tar_path_traversal_refused(tmp_path):
+    (tmp_path / "evil.tar").write_bytes(_tar_bytes({"../escape.txt": b"x"}))
+    with tarfile.open(tmp_path / "evil.tar") as t, pytest.raises(RuntimeError):
+        prepare_imagenet._safe_extract(t, str(tmp_path / "out"))
+
+
+def test_job_json_has_launch_line_and_directories(tmp_path, monkeypatch):
+    monkeypatch.setenv("DDL_JOBS_DIR", str(tmp_path))
+    cl = json.load(open(os.path.join(ROOT, "deploy/cluster/cluster.json")))
+    job = submit_job.build_job("j1", cl, 2, 8, "examples/imagenet_pytorch.py", True, 3, {"FOO": "bar"})
+    line = job["properties"]["customToolkitSettings"]["commandLine"]
+    assert "-np 16" in line and "--hostfile" in line and "-x FAKE=True" in line and "-x FOO=bar" in line
+    assert "-x DISTRIBUTED=True" in line and "-x EPOCHS=3" in line
+    assert job["hosts"] == ["node0 slots=8", "node1 slots=8"]
+    ids = [d["id"] for d in job["properties"]["inputDirectories"]]
+    assert ids == ["SCRIPTS", "TRAIN", "TEST"] and job["properties"]["outputDirectories"][0]["id"] == "MODEL"
+    sb = submit_job.render_sbatch(job, str(tmp_path))
+    assert "#SBATCH --nodes=2" in sb and "--gpus-per-node=8" in sb
+    with pytest.raises(ValueError):
+        submit_job.build_job("j2", cl, 3, 8, "x.py", True, 1, {})
+
+
+def test_submit_cli_dry_run(tmp_path, monkeypatch, capsys):
+    monkeypatch.setenv("DDL_JOBS_DIR", str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    assert submit_job.main(["create", "--name", "t", "--nodes", "1", "--ppn", "2", "--fake"]) == 0
+    assert os.path.isfile(tmp_path / "t" / "job.json") and (tmp_path / "t" / "hostfile").read_text() == "node0 slots=2\n"
+    assert submit_job.main(["submit", "t", "--dry-run"]) == 0
+    assert "launch.run -np 2" in capsys.readouterr().out
+    assert submit_job.main(["delete", "t"]) == 0 and not os.path.exists(tmp_path / "t")
+
+
+def test_local_smoke_command_lines(capsys):
+    assert local_smoke.main(["--dry-run", "--np", "2", "-x", "BATCHSIZE=8"]) == 0
+    out = capsys.readouterr().out
+    assert "-np 2 -H localhost:2" in out and "-x FAKE=True" in out and "-x BATCHSIZE=8" in out
+    assert local_smoke.main(["--dry-run", "--build", "img", "--push"]) == 0
+    out = capsys.readouterr().out
+    assert "docker build -t img" in out and "--device=/dev/kfd" in out and "docker push img" in out
+
+
+def test_create_resources_init_writes_cluster_and_env(tmp_path, monkeypatch):
+    out = tmp_path / "cluster.json"
+    monkeypatch.chdir(tmp_path)
+    assert create_resources.main(["init", "--nodes", "a,b,c", "--gpus-per-node", "4", "--data", "/d",
+                                  "--out", str(out)]) == 0
+    cl = json.loads(out.read_text())
+    assert cl["nodes"] == ["a", "b", "c"] and cl["gpus_per_node"] == 4 and cl["mounts"]["train"] == "/d/train"
