@@ -108,6 +108,8 @@ class Estimator:
                 for h in hooks:
                     h.after_create_session(self.state)
                 created = True
+                # restore / broadcast rewrote the variables in place: rebuild the step on them
+                spec = self.model_fn(features, labels, ModeKeys.TRAIN, self.params)
             for h in hooks:
                 h.before_run(self.global_step)
             spec.train_op()

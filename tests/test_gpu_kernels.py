@@ -425,3 +425,39 @@ def test_pack_scale_cast_roundtrip():
     for t, b in zip(ts, back):
         assert torch.allclose(b, t, rtol=1e-2, atol=2e-2)
     del keep, keep2
+
+
+def test_fused_lars_matches_cpu_reference_path():
+    """K15 kernels (segmented norms + LARS update) against the optimizer's plain-PyTorch path."""
+    from distributeddeeplearning_amd.optim import FusedLARS
+
+    def run(device):
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 48), torch.nn.ReLU(), torch.nn.Linear(48, 16))
+        net.to(device)
+        opt = FusedLARS(net.named_parameters(), lr=0.2, momentum=0.9, weight_decay=1e-3)
+        g = torch.Generator().manual_seed(6)
+        for _ in range(3):
+            x = torch.randn(32, 64, generator=g).to(device)
+            opt.zero_grad()
+            net(x).pow(2).mean().backward()
+            opt.step()
+        return [p.detach().cpu() for p in net.parameters()]
+
+    for a, b in zip(run(DEV), run("cpu")):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_nchw_to_nhwc_normalize():
+    from distributeddeeplearning_amd.ops import kernels
+
+    kernels.require()
+    x = torch.rand(3, 3, 17, 19, device=DEV)
+    mean, sd = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    out = kernels.nchw_to_nhwc_normalize(x, mean, sd)
+    ref = (x - torch.tensor(mean, device=DEV).view(1, 3, 1, 1)) / torch.tensor(sd, device=DEV).view(1, 3, 1, 1)
+    assert out.shape == x.shape and out.stride(1) == 1
+    assert torch.allclose(out.float(), ref, atol=2e-2)
+    u8 = (x * 255).to(torch.uint8)
+    out8 = kernels.nchw_to_nhwc_normalize(u8, mean, sd, in_scale=1.0 / 255)
+    assert torch.allclose(out8.float(), ref, atol=3e-2)
