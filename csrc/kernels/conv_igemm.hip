@@ -21,6 +21,7 @@
 // lanes, optionally adding a residual tensor (backward shortcut fusion) and emitting per-tile
 // per-channel sum / sum-of-squares partials for BatchNorm (K6 fused: saves one full read of y).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -131,32 +132,43 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     const int KT = nr * ns * cpt;
     int kr = r0, ks = s0, kc = 0;      // tap / channel-block counters of the tile being fetched
 
-    u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
-    auto fetch = [&](int) {
+    // Operand staging: the next tile's loads are issued before the current tile is consumed.
+    // Tap geometry (bounds, dilation, pixel offset) is recomputed only when the filter tap
+    // changes; the channel-block step rides in the buffer instruction's scalar offset.
+    constexpr unsigned INVALID = 0x80000000u;
+    const int xs_h2 = (int)(p.xs_h * 2), xs_w2 = (int)(p.xs_w * 2);
+    unsigned a_voff[A_LOADS];
+    auto retap = [&]() {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             int th = a_h0[i] + kr, tw = a_w0[i] + ks;
             bool ok = (th >= 0) & (tw >= 0) & (((th | tw) & idil_mask) == 0);
             int hi = th >> p.idil_log2, wi = tw >> p.idil_log2;
             ok = ok & (hi < p.Hin) & (wi < p.Win);
-            long long e = a_base[i] + (long long)hi * p.xs_h + (long long)wi * p.xs_w + kc * BK;
-            a_reg[i] = buf_load16(xr, ok ? (unsigned)(e * 2) : 0x80000000u);
+            a_voff[i] = ok ? (unsigned)((int)(a_base[i] * 2) + hi * xs_h2 + wi * xs_w2) : INVALID;
         }
-        const unsigned wk = (unsigned)(((kr * p.S + ks) * p.C + kc * BK) * 2);
+    };
+    auto fetch = [&](u32x4 (&ar)[A_LOADS], u32x4 (&br)[B_LOADS]) {
+        if (kc == 0) retap();
+        const int kco = kc * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            ar[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)a_voff[i], kco, 0);
+        const int wk = ((kr * p.S + ks) * p.C + kc * BK) * 2;
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
-            b_reg[i] = buf_load16(wr, b_off[i] == 0x80000000u ? b_off[i] : b_off[i] + wk);
+            br[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)b_off[i], wk, 0);
         if (++kc == cpt) { kc = 0; ks += tstep; if (ks >= p.S) { ks = s0; kr += tstep; } }
     };
-    auto stash = [&](int stage) {
+    auto stash = [&](int stage, const u32x4 (&ar)[A_LOADS], const u32x4 (&br)[B_LOADS]) {
         unsigned char* As = smem + stage * STAGE;
         unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
-            *reinterpret_cast<u32x4*>(As + lds_off<BK>(row0 + i * RPP, ch)) = a_reg[i];
+            *reinterpret_cast<u32x4*>(As + lds_off<BK>(row0 + i * RPP, ch)) = ar[i];
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
-            *reinterpret_cast<u32x4*>(Bs + lds_off<BK>(row0 + i * RPP, ch)) = b_reg[i];
+            *reinterpret_cast<u32x4*>(Bs + lds_off<BK>(row0 + i * RPP, ch)) = br[i];
     };
 
     f32x4 acc[FN][FM];
@@ -165,14 +177,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
-    stash(0);
-    __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) fetch(kt + 1);
-        const unsigned char* As = smem + cur * STAGE;
+    auto compute = [&](int stage) {
+        const unsigned char* As = smem + stage * STAGE;
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -189,7 +196,21 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
                 for (int j = 0; j < FM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[i], xa[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) stash(cur ^ 1);
+    };
+
+    // one tile of loads in flight per block (a second register set was measured: the extra
+    // VGPRs cost more occupancy than the deeper prefetch returned — profiles/r1_notes.md)
+    u32x4 a0[A_LOADS], b0[B_LOADS];
+    if (KT > 0) {
+        fetch(a0, b0);
+        stash(0, a0, b0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) fetch(a0, b0);
+        compute(cur);
+        if (kt + 1 < KT) stash(cur ^ 1, a0, b0);
         __syncthreads();
     }
 
@@ -327,7 +348,11 @@ extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void*
         p.tiles_per_class = (p.Mc + 127) / 128;
         p.tiles_m = 4 * p.tiles_per_class;
     }
-    const bool bk64 = (C % 64 == 0);
+    static const int force_bk = getenv("DDL_CONV_BK") ? atoi(getenv("DDL_CONV_BK")) : 0;  // tuning knob
+    // K-tile depth per shape class, from benchmarks/kernel_bench.py on MI355X (profiles/): the
+    // shallower tile wins (4 blocks per CU instead of 2) except for the deepest reductions
+    const bool deep = (R * S == 1) ? (C >= 2048) : (C < 128 || C >= 512);
+    const bool bk64 = (C % 64 == 0) && force_bk != 32 && (force_bk == 64 || deep);
     if (N <= 64) {
         p.tiles_n = (N + 63) / 64;
         return bk64 ? launch_cfg<128, 64, 64>(p, stream) : launch_cfg<128, 64, 32>(p, stream);

@@ -101,11 +101,20 @@ __global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const double* __re
                                                              float* __restrict__ shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int p = 0; p < P; ++p) {
+    double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0, u1 = 0.0, u2 = 0.0, w1 = 0.0, w2 = 0.0;
+    int p = 0;
+    for (; p + 3 < P; p += 4) {  // independent chains: the loads of one round overlap
+        s1 += folded[((long long)p * 2) * C + c];       s2 += folded[((long long)p * 2 + 1) * C + c];
+        t1 += folded[((long long)p * 2 + 2) * C + c];   t2 += folded[((long long)p * 2 + 3) * C + c];
+        u1 += folded[((long long)p * 2 + 4) * C + c];   u2 += folded[((long long)p * 2 + 5) * C + c];
+        w1 += folded[((long long)p * 2 + 6) * C + c];   w2 += folded[((long long)p * 2 + 7) * C + c];
+    }
+    for (; p < P; ++p) {
         s1 += folded[((long long)p * 2) * C + c];
         s2 += folded[((long long)p * 2 + 1) * C + c];
     }
+    s1 = (s1 + t1) + (u1 + w1);
+    s2 = (s2 + t2) + (u2 + w2);
     const double n = (double)M;
     const double mean = s1 / n;
     double m2 = s2 - s1 * mean;
@@ -216,11 +225,22 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __re
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     float s1 = 0.f, s2 = 0.f;
-    if (c < C)
-        for (int t = ty; t < G; t += 16) {
+    if (c < C) {
+        float p1 = 0.f, p2 = 0.f, q1 = 0.f, q2 = 0.f, r1 = 0.f, r2 = 0.f;
+        int t = ty;
+        for (; t + 48 < G; t += 64) {  // four independent chains per lane
+            s1 += partial[((long long)t * 2) * C + c];          s2 += partial[((long long)t * 2 + 1) * C + c];
+            p1 += partial[((long long)(t + 16) * 2) * C + c];   p2 += partial[((long long)(t + 16) * 2 + 1) * C + c];
+            q1 += partial[((long long)(t + 32) * 2) * C + c];   q2 += partial[((long long)(t + 32) * 2 + 1) * C + c];
+            r1 += partial[((long long)(t + 48) * 2) * C + c];   r2 += partial[((long long)(t + 48) * 2 + 1) * C + c];
+        }
+        for (; t < G; t += 16) {
             s1 += partial[((long long)t * 2) * C + c];
             s2 += partial[((long long)t * 2 + 1) * C + c];
         }
+        s1 = (s1 + p1) + (q1 + r1);
+        s2 = (s2 + p2) + (q2 + r2);
+    }
     a1[ty][tx] = s1; a2[ty][tx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
@@ -535,9 +555,9 @@ extern "C" int ddl_bn_stats_partial(const void* y, void* partial, long long M, i
 
 // workspace (doubles) needed by ddl_bn_fwd_finalize for T tiles of C channels
 extern "C" long long ddl_bn_fold_slices(int T) {
-    int P = T / 32;
+    int P = T / 64;
     if (P < 1) P = 1;
-    if (P > 64) P = 64;
+    if (P > 32) P = 32;
     return P;
 }
 

@@ -86,9 +86,14 @@ class BatchNormAct(nn.Module):
         return "{channels}, relu={relu}, momentum={momentum}, eps={eps}".format(**self.__dict__)
 
 
+# ResNet.forward bumps every BatchNorm's ``num_batches_tracked`` with ONE multi-tensor add instead
+# of 53 tiny launches; blocks used on their own keep the per-layer increment.
+_NBT_BATCHED = [False]
+
+
 def _cba(conv, bn, x, residual=None):
     """conv -> BatchNorm(+residual)(+ReLU) through the fused functional op."""
-    if bn.training:
+    if bn.training and not _NBT_BATCHED[0]:
         bn.num_batches_tracked += 1
     return ops.conv_bn_act(x, conv.weight, conv.stride, conv.padding, bn.weight, bn.bias,
                            bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps,
@@ -96,7 +101,7 @@ def _cba(conv, bn, x, residual=None):
 
 
 def _unit(conv, bn):
-    if bn.training:
+    if bn.training and not _NBT_BATCHED[0]:
         bn.num_batches_tracked += 1
     return (conv.weight, conv.stride, conv.padding, bn.weight, bn.bias, bn.running_mean,
             bn.running_var)
@@ -190,10 +195,19 @@ class ResNet(nn.Module):
         self.feature_dim = cin
 
     def forward(self, x):
-        x = _cba(self.conv1, self.bn1, x)
-        x = ops.maxpool3x3s2(x)
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        return self.fc(ops.global_avgpool(x))
+        batched = self.training and not _NBT_BATCHED[0]
+        if batched:
+            counters = [m.num_batches_tracked for m in self.modules() if isinstance(m, BatchNormAct)]
+            torch._foreach_add_(counters, 1)
+            _NBT_BATCHED[0] = True
+        try:
+            x = _cba(self.conv1, self.bn1, x)
+            x = ops.maxpool3x3s2(x)
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            return self.fc(ops.global_avgpool(x))
+        finally:
+            if batched:
+                _NBT_BATCHED[0] = False
 
     def to_compute(self, device, dtype=torch.bfloat16):
         """Move to ``device`` with conv/fc weights in ``dtype`` (KRSC) and BatchNorm + fc bias
