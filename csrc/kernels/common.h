@@ -2,6 +2,7 @@
 // Wave = 64 lanes; all vector accesses are 16 B per lane where alignment allows.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <stdint.h>
 
 #define DDL_OK 0
@@ -22,6 +23,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // RNE, NaN-preserving
 
+__device__ __forceinline__ void load8f(const float* p, float* v) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+
+// The one BN affine used by forward and by the backward's mask recomputation: identical
+// rounding on both sides, so "z > 0" can be re-derived from y without reading z.
+__device__ __forceinline__ float bn_affine(float v, float sc, float sh) { return __builtin_fmaf(v, sc, sh); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -33,9 +44,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-static inline int ddl_launch_status() {
-    return hipGetLastError() == hipSuccess ? DDL_OK : DDL_ELAUNCH;
+static inline int ddl_launch_status_at(const char* file, int line) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return DDL_OK;
+    fprintf(stderr, "[ddl] kernel launch failed at %s:%d: %s\n", file, line, hipGetErrorString(e));
+    return DDL_ELAUNCH;
 }
+#define ddl_launch_status() ddl_launch_status_at(__FILE__, __LINE__)
 static inline bool ddl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Grid sizing for memory-bound grid-stride kernels: cap at 256 CUs x 8 blocks.

@@ -39,6 +39,10 @@ struct IGemmParams {
     int tiles_m, tiles_n;
     int addend_sub2;  // addend is [B][Hout/2][Wout/2][N]: added at even (h, w) pixels only
     int parity, tiles_per_class, Mc;  // stride-2 backward-data: M ordered by output-pixel parity class
+    // fused backward epilogues (EPI 2 / 3), all tensors [M][N] like y:
+    const bf16_t* ep_y;      // EPI 2: pre-BatchNorm activation of the layer whose output gradient this is
+    const float* ep_fcoef;   // EPI 2: [2][N] forward scale | shift of that BatchNorm (ReLU mask = scale*y+shift > 0)
+    const bf16_t* ep_mask;   // EPI 3: ReLU output; the result is zeroed where it is <= 0
 };
 
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -52,8 +56,14 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
     return row * 64 + ((ch ^ ((0 - (row >> 2)) & 3)) << 4);
 }
 
-template <int BM, int BN, int BK, bool STATS, bool ADDEND>
+// EPI: 0 plain store; 1 forward BatchNorm statistics (sum y, sum y^2 per tile and channel);
+//      2 backward-data feeding a BatchNorm+ReLU backward: g = dz * relu'(bn(y)) is stored and the
+//        tile's sum g / sum g*y partials are emitted (replaces the separate K8a reduce pass);
+//      3 backward-data whose consumer is a ReLU: store dz * (mask > 0) so that the consumer's
+//        backward needs neither the mask tensor nor a masked copy of the gradient.
+template <int BM, int BN, int BK, int EPI, bool ADDEND>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p) {
+    constexpr bool STATS = EPI == 1 || EPI == 2;
     constexpr int CPR = BK / 8;            // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;         // rows covered per pass of the 256 threads
     constexpr int A_LOADS = BM / RPP, B_LOADS = BN / RPP;
@@ -230,9 +240,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     constexpr int OCPR = BN / 8, ORPP = 256 / OCPR, OITER = BM / ORPP;
     const int oc = tid % OCPR, orow0 = tid / OCPR;
     const int n = n0 + oc * 8;
-    float s1[8], s2[8];
+    float s1[8], s2[8], fsc[8], fsh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; fsc[e] = 0.f; fsh[e] = 0.f; }
+    if (EPI == 2 && n < p.N) { load8f(p.ep_fcoef + n, fsc); load8f(p.ep_fcoef + p.N + n, fsh); }
 #pragma unroll
     for (int it = 0; it < OITER; ++it) {
         int row = orow0 + it * ORPP, m = m0 + row;
@@ -260,8 +271,24 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
                     for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(a[e]));
                 }
             }
+            if (EPI == 3) {
+                bf16x8 zm = *reinterpret_cast<const bf16x8*>(p.ep_mask + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = bf2f(zm[e]) > 0.f ? v[e] : f2bf(0.f);
+            }
+            if (EPI == 2) {
+                bf16x8 yv = *reinterpret_cast<const bf16x8*>(p.ep_y + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float yf = bf2f(yv[e]);
+                    bool on = bn_affine(yf, fsc[e], fsh[e]) > 0.f;
+                    v[e] = on ? v[e] : f2bf(0.f);
+                    float g = bf2f(v[e]);
+                    s1[e] += g; s2[e] += g * yf;
+                }
+            }
             *reinterpret_cast<bf16x8*>(p.y + o) = v;
-            if (STATS) {
+            if (EPI == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float f = bf2f(v[e]); s1[e] += f; s2[e] += f * f; }
             }
@@ -296,9 +323,12 @@ template <int BM, int BN, int BK>
 int launch_cfg(const IGemmParams& p, hipStream_t stream) {
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     if (p.stats && p.addend) return DDL_EINVAL;
-    if (p.stats) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, true, false>), grid, block, 0, stream, p);
-    else if (p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, false, false>), grid, block, 0, stream, p);
+    if (p.ep_y) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 2, false>), grid, block, 0, stream, p);
+    else if (p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, true>), grid, block, 0, stream, p);
+    else if (p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, false>), grid, block, 0, stream, p);
+    else if (p.stats) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 1, false>), grid, block, 0, stream, p);
+    else if (p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, false>), grid, block, 0, stream, p);
     return ddl_launch_status();
 }
 
@@ -307,11 +337,22 @@ int launch_cfg(const IGemmParams& p, hipStream_t stream) {
 // Number of M tiles the forward kernel uses for a problem (so callers can size `stats`).
 extern "C" int ddl_conv_igemm_tiles_m(long long M) { return (int)((M + 127) / 128); }
 
-extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void* addend, void* stats,
-                              long long x_numel, long long w_numel,
-                              int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
-                              int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
-                              int addend_sub2, hipStream_t stream) {
+static bool igemm_parity(int idil, int ostride, int Hout, int Wout) {
+    return idil == 2 && ostride == 1 && (Hout % 2) == 0 && (Wout % 2) == 0;
+}
+
+// M tiles of a backward-data launch (parity-class ordering pads every class to whole tiles).
+extern "C" int ddl_conv_igemm_tiles_m_bwd(long long M, int Hout, int Wout, int idil, int ostride) {
+    if (igemm_parity(idil, ostride, Hout, Wout)) return 4 * (int)((M / 4 + 127) / 128);
+    return (int)((M + 127) / 128);
+}
+
+extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const void* addend, void* stats,
+                                 long long x_numel, long long w_numel,
+                                 int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                 int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
+                                 int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
+                                 hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || N <= 0 || R <= 0 || S <= 0) return DDL_EINVAL;
     if (C % 32 != 0 || N % 8 != 0) return DDL_EINVAL;
     if (idil != 1 && idil != 2 && idil != 4) return DDL_EINVAL;
@@ -319,6 +360,10 @@ extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void*
     if (x_numel * 2 >= 0x7fffffffLL || w_numel * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     if (w_numel < (long long)N * R * S * C) return DDL_EINVAL;
     if (!ddl_aligned16(x) || !ddl_aligned16(w) || !ddl_aligned16(y) || (addend && !ddl_aligned16(addend))) return DDL_EALIGN;
+    if ((ep_y && !ddl_aligned16(ep_y)) || (ep_fcoef && !ddl_aligned16(ep_fcoef)) || (ep_mask && !ddl_aligned16(ep_mask))) return DDL_EALIGN;
+    // fused BatchNorm-backward reduce needs y, the forward coefficients and the partial buffer together
+    if ((ep_y != nullptr) != (ep_fcoef != nullptr) || (ep_y && (!stats || addend || ep_mask))) return DDL_EINVAL;
+    if (ep_mask && stats) return DDL_EINVAL;
     if ((xs_b % 8) || (xs_h % 8)) return DDL_EALIGN;
     // every tap address must be 16-byte aligned: either pixels are >= 8 elements apart, or (S == 1,
     // undilated) only multiples of ostride are visited and those are
@@ -333,6 +378,7 @@ extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void*
     IGemmParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
     p.addend = (const bf16_t*)addend; p.stats = (float*)stats;
+    p.ep_y = (const bf16_t*)ep_y; p.ep_fcoef = (const float*)ep_fcoef; p.ep_mask = (const bf16_t*)ep_mask;
     p.x_bytes = (unsigned)(x_numel * 2); p.w_bytes = (unsigned)(w_numel * 2);
     p.Hin = Hin; p.Win = Win; p.C = C; p.xs_b = xs_b; p.xs_h = xs_h; p.xs_w = xs_w;
     p.Hout = Hout; p.Wout = Wout; p.N = N; p.M = (int)M;
@@ -342,7 +388,7 @@ extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void*
     p.addend_sub2 = addend_sub2;
     p.tiles_m = (int)((M + 127) / 128);
     p.parity = 0; p.tiles_per_class = 0; p.Mc = 0;
-    if (idil == 2 && ostride == 1 && (Hout % 2) == 0 && (Wout % 2) == 0 && !stats) {
+    if (igemm_parity(idil, ostride, Hout, Wout) && (!stats || ep_y)) {
         p.parity = 1;
         p.Mc = (int)(M / 4);
         p.tiles_per_class = (p.Mc + 127) / 128;
@@ -359,4 +405,13 @@ extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void*
     }
     p.tiles_n = (N + 127) / 128;
     return bk64 ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
+}
+
+extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void* addend, void* stats,
+                              long long x_numel, long long w_numel,
+                              int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                              int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
+                              int addend_sub2, hipStream_t stream) {
+    return ddl_conv_igemm_ex(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
+                             N, R, S, ostride, pad, pad_w, idil, addend_sub2, nullptr, nullptr, nullptr, stream);
 }

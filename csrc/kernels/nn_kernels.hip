@@ -9,16 +9,6 @@
 
 namespace {
 
-__device__ __forceinline__ void load8f(const float* p, float* v) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
-}
-
-// The one BN affine used by forward and by the backward's mask recomputation: identical
-// rounding on both sides, so "z > 0" can be re-derived from y without reading z.
-__device__ __forceinline__ float bn_affine(float v, float sc, float sh) { return __builtin_fmaf(v, sc, sh); }
-
 // ---------------------------------------------------------------------------------------------
 // K6a: standalone statistics partials [T][2][C] over tiles of `rows_per_tile` rows (used when the
 // producer is not our conv kernel).  256 threads = (C/8 chunk columns) x row lanes.
@@ -58,8 +48,9 @@ __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const bf16_t* __r
 // stage 2 (one thread per channel) folds the P slices, updates the running statistics (unbiased
 // variance, like torch) and emits the fused scale/shift of K7.
 // ---------------------------------------------------------------------------------------------
+template <typename OutT>
 __global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restrict__ partial, int T, int C, int P,
-                                                           double* __restrict__ folded /*[P][2][C]*/) {
+                                                           OutT* __restrict__ folded /*[P][2][C]*/) {
     __shared__ double r1[4][64], r2[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
@@ -88,8 +79,8 @@ __global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restr
     if (ty == 0 && c < C) {
         s1 = (r1[0][tx] + r1[1][tx]) + (r1[2][tx] + r1[3][tx]);
         s2 = (r2[0][tx] + r2[1][tx]) + (r2[2][tx] + r2[3][tx]);
-        folded[((long long)blockIdx.y * 2) * C + c] = s1;
-        folded[((long long)blockIdx.y * 2 + 1) * C + c] = s2;
+        folded[((long long)blockIdx.y * 2) * C + c] = (OutT)s1;
+        folded[((long long)blockIdx.y * 2 + 1) * C + c] = (OutT)s2;
     }
 }
 
@@ -568,7 +559,7 @@ extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long 
     CHK((long long)T * rows_per_tile >= M && (long long)(T - 1) * rows_per_tile < M, DDL_EINVAL);
     CHK((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, DDL_EALIGN);
     const int P = (int)ddl_bn_fold_slices(T);
-    hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
+    hipLaunchKernelGGL(bn_stats_fold_kernel<double>, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
                        (double*)workspace);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)workspace, P, C, M,
                        (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
@@ -617,9 +608,20 @@ extern "C" int ddl_bn_bwd_reduce(const void* dz, const void* y, const void* z, c
     return ddl_launch_status();
 }
 
+// `workspace` (optional, [ddl_bn_fold_slices(G)][2][C] floats): long partial tables (the per-tile
+// partials of a fused conv epilogue) are first folded by many CUs.
 extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long M, const void* gamma, const void* mean,
-                                   const void* invstd, void* dgamma, void* dbeta, void* coef, int accumulate, hipStream_t stream) {
+                                   const void* invstd, void* dgamma, void* dbeta, void* coef, int accumulate,
+                                   void* workspace, hipStream_t stream) {
     CHK(partial && gamma && mean && invstd && dgamma && dbeta && coef && G > 0 && C > 0 && M > 0, DDL_EINVAL);
+    if (workspace && G > 256) {
+        const int P = (int)ddl_bn_fold_slices(G);
+        hipLaunchKernelGGL(bn_stats_fold_kernel<float>, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const float*)partial, G, C,
+                           P, (float*)workspace);
+        if (ddl_launch_status() != DDL_OK) return DDL_ELAUNCH;
+        partial = workspace;
+        G = P;
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, G, C, M,
                        (const float*)gamma, (const float*)mean, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef, accumulate);
     return ddl_launch_status();

@@ -107,15 +107,25 @@ def _unit(conv, bn):
             bn.running_var)
 
 
-def _block(x, pairs, downsample):
-    """Run a residual block through ``ops.residual_block`` (one fused autograd node on GPU)."""
-    bn0 = pairs[0][1]
+def _block_spec(pairs, downsample):
     units = [_unit(c, b) for c, b in pairs]
     ds = None
     if downsample is not None:
         u = _unit(downsample[0], downsample[1])
         ds = (u[0], u[1]) + u[3:]
+    return units, ds
+
+
+def _block(x, pairs, downsample):
+    """Run a residual block through ``ops.residual_block`` (one fused autograd node on GPU)."""
+    bn0 = pairs[0][1]
+    units, ds = _block_spec(pairs, downsample)
     return ops.residual_block(x, units, ds, bn0.training, bn0.momentum, bn0.eps)
+
+
+def _has_hooks(m):
+    return bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or
+                m._backward_pre_hooks)
 
 
 class Linear(nn.Module):
@@ -151,9 +161,11 @@ class Bottleneck(nn.Module):
         self.bn3 = BatchNormAct(filters * 4, relu=True, zero_init=zero_init_residual)
         self.downsample = _Downsample(cin, filters * 4, stride) if project else None
 
+    def pairs(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+
     def forward(self, x):
-        return _block(x, [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)],
-                      self.downsample)
+        return _block(x, self.pairs(), self.downsample)
 
 
 class BasicBlock(nn.Module):
@@ -167,8 +179,11 @@ class BasicBlock(nn.Module):
         self.bn2 = BatchNormAct(filters, relu=True, zero_init=zero_init_residual)
         self.downsample = _Downsample(cin, filters, stride) if project else None
 
+    def pairs(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+
     def forward(self, x):
-        return _block(x, [(self.conv1, self.bn1), (self.conv2, self.bn2)], self.downsample)
+        return _block(x, self.pairs(), self.downsample)
 
 
 class ResNet(nn.Module):
@@ -193,6 +208,7 @@ class ResNet(nn.Module):
             setattr(self, "layer%d" % (gi + 1), nn.Sequential(*blocks))
         self.fc = Linear(cin, num_classes)
         self.feature_dim = cin
+        self.chain_blocks = True  # see _trunk
 
     def forward(self, x):
         batched = self.training and not _NBT_BATCHED[0]
@@ -203,11 +219,26 @@ class ResNet(nn.Module):
         try:
             x = _cba(self.conv1, self.bn1, x)
             x = ops.maxpool3x3s2(x)
-            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            x = self._trunk(x)
             return self.fc(ops.global_avgpool(x))
         finally:
             if batched:
                 _NBT_BATCHED[0] = False
+
+    def _trunk(self, x):
+        """The 4 block groups.  Without module hooks on them the 16 (ResNet-50) blocks run as one
+        ``ops.residual_chain`` — no intermediate activation escapes, so the fused block nodes
+        may hand each other ReLU-masked gradients; with hooks, module by module."""
+        layers = (self.layer1, self.layer2, self.layer3, self.layer4)
+        blocks = [b for layer in layers for b in layer]
+        if not self.chain_blocks or any(_has_hooks(m) for m in blocks) or \
+                any(_has_hooks(m) for m in layers):
+            for layer in layers:
+                x = layer(x)
+            return x
+        bn0 = blocks[0].bn1
+        specs = [_block_spec(b.pairs(), b.downsample) for b in blocks]
+        return ops.residual_chain(x, specs, bn0.training, bn0.momentum, bn0.eps)
 
     def to_compute(self, device, dtype=torch.bfloat16):
         """Move to ``device`` with conv/fc weights in ``dtype`` (KRSC) and BatchNorm + fc bias

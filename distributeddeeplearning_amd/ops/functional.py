@@ -121,6 +121,23 @@ def residual_block(x, units, downsample, training, momentum=0.1, eps=1e-5):
     return cur
 
 
+def residual_chain(x, blocks, training, momentum=0.1, eps=1e-5):
+    """Consecutive residual blocks, ``blocks`` = list of ``(units, downsample)`` as taken by
+    :func:`residual_block`.  The intermediate activations are not exposed, which lets the HIP
+    path pass ReLU-masked gradients between the fused block nodes
+    (``hip_ops.residual_chain``); elsewhere it is just the loop over the blocks."""
+    if use_hip(x):
+        from . import hip_ops
+
+        if all(hip_ops.residual_block_supported(
+                [u[0] for u in units] + ([ds[0]] if ds is not None else []))
+               for units, ds in blocks):
+            return hip_ops.residual_chain(x, blocks, training, momentum, eps)
+    for units, ds in blocks:
+        x = residual_block(x, units, ds, training, momentum, eps)
+    return x
+
+
 def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
                   relu=True, residual=None):
     """``act(bn(x) [+ residual])`` with act = ReLU or identity; running stats updated in place

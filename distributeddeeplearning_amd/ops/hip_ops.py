@@ -203,11 +203,13 @@ def _conv_fwd(x, w, stride, padding, want_stats):
     return y, stats
 
 
-def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False):
+def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False, mask_src=None):
+    """dx of a convolution; ``addend`` is summed in the epilogue (shortcut gradient) and
+    ``mask_src`` (the ReLU output that IS the conv input) zeroes dx where it is <= 0."""
     B, C, H, W = x_shape
     _, _, R, S = w.shape
     wt = _WT.get(w)
-    if R == 1 and S == 1 and stride == 2 and padding == 0 and addend is None:
+    if R == 1 and S == 1 and stride == 2 and padding == 0 and addend is None and mask_src is None:
         # 1x1 stride 2: only even pixels receive a gradient; compute them as a plain GEMM and
         # scatter (the fused block never gets here: it hands the compact result to the next
         # backward-data kernel as a sub-sampled addend)
@@ -216,8 +218,23 @@ def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False)
         return dx
     dx = _empty_nhwc(B, C, H, W, dy.device)
     K.conv_igemm(dy, _geom(dy), wt, dx, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
-                 addend=addend, addend_sub2=addend_sub2)
+                 addend=addend, addend_sub2=addend_sub2, ep_mask=mask_src)
     return dx
+
+
+def _conv_dgrad_bn(dy, w, x_shape, stride, padding, y_prev, fcoef_prev):
+    """Backward-data whose output is the gradient of ``relu(bn(y_prev))``: the kernel stores the
+    ReLU-masked gradient g and the per-tile partials of sum g / sum g*y_prev, i.e. the reduce
+    pass of that BatchNorm's backward (K8a) rides in the epilogue.  Returns (g, partial)."""
+    B, C, H, W = x_shape
+    _, _, R, S = w.shape
+    wt = _WT.get(w)
+    T = K.conv_tiles_m_bwd(B * H * W, H, W, stride, 1)
+    partial = torch.empty((T, 2, C), dtype=torch.float32, device=dy.device)
+    g = _empty_nhwc(B, C, H, W, dy.device)
+    K.conv_igemm(dy, _geom(dy), wt, g, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
+                 stats=partial, ep_y=y_prev, ep_fcoef=fcoef_prev)
+    return g, partial
 
 
 def _conv_dgrad_1x1s2_compact(dy, w):
@@ -269,21 +286,27 @@ def _bn_fwd(y, gamma, beta, residual, stats, rmean, rvar, training, momentum, ep
     return z, coeffs
 
 
-def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True):
+def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True, partial=None,
+            premasked=False):
     """(dy, dgamma, dbeta, g) with g = dz masked by the ReLU (None unless want_g and relu).
 
     With ``beta`` given and direct gradients enabled, dgamma/dbeta are accumulated by the
-    finalize kernel straight into ``gamma.grad`` / ``beta.grad`` (returned as None)."""
+    finalize kernel straight into ``gamma.grad`` / ``beta.grad`` (returned as None).
+    ``partial``: the reduce pass already ran in the producing kernel's epilogue (``dz`` is then
+    the masked gradient).  ``premasked``: ``dz`` already carries the ReLU mask."""
     B, C, H, W = y.shape
     M = B * H * W
     dev = y.device
-    G = K.bn_bwd_blocks(M)
-    partial = torch.empty((G, 2, C), dtype=torch.float32, device=dev)
     # ReLU mask: from the stored activation when a residual was added before the ReLU, else
     # recomputed from y with the forward scale/shift (z is then never read)
-    mask = 0 if not relu else (1 if has_res else 2)
+    mask = 0 if (not relu or premasked or partial is not None) else (1 if has_res else 2)
     fco = coeffs[2:4] if mask == 2 else None
-    K.bn_bwd_reduce(dz, y, z if mask == 1 else None, fco, partial, M, C, mask, G)
+    if partial is None:
+        G = K.bn_bwd_blocks(M)
+        partial = torch.empty((G, 2, C), dtype=torch.float32, device=dev)
+        K.bn_bwd_reduce(dz, y, z if mask == 1 else None, fco, partial, M, C, mask, G)
+    else:
+        G = partial.shape[0]
     coef = torch.empty((3, C), dtype=torch.float32, device=dev)
     direct = beta is not None and _DIRECT["on"] and _direct_grad_ok(gamma) and \
         _direct_grad_ok(beta) and gamma.grad.dtype == torch.float32 and \
@@ -297,9 +320,9 @@ def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True):
         K.bn_bwd_finalize(partial, G, C, M, gamma, coeffs[0], coeffs[1], dgb[0], dgb[1], coef)
         dg, db = dgb[0], dgb[1]
     dy = torch.empty_like(y)
-    g = torch.empty_like(y) if (want_g and relu) else None
+    g = torch.empty_like(y) if (want_g and mask != 0) else None
     K.bn_bwd_apply(dz, y, z if mask == 1 else None, fco, coef, dy, g, M, C, mask)
-    if want_g and not relu:
+    if want_g and mask == 0:
         g = dz
     if direct:
         _notify(gamma)
@@ -467,7 +490,7 @@ class ResidualBlockFn(Function):
 
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
-        units, strides, pads, has_ds, ds_stride, training, momentum, eps = cfg
+        units, strides, pads, has_ds, ds_stride, training, momentum, eps = cfg[:8]
         x = _as_nhwc(x)
         n = units + (1 if has_ds else 0)
         groups = [tensors[5 * i: 5 * i + 5] for i in range(n)]
@@ -500,7 +523,8 @@ class ResidualBlockFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        units, strides, pads, has_ds, ds_stride, training, momentum, eps = ctx.cfg
+        units, strides, pads, has_ds, ds_stride, training, momentum, eps = ctx.cfg[:8]
+        premask_in, grad_premasked = ctx.cfg[8], ctx.cfg[9]
         if not training:
             raise K.KernelError("fused residual block: backward in eval mode is not supported")
         saved = ctx.saved_tensors
@@ -518,18 +542,24 @@ class ResidualBlockFn(Function):
 
         dz = dout
         g_short = None
+        fused = None  # BatchNorm-backward partials produced by the previous dgrad's epilogue
         for i in range(units - 1, -1, -1):
             w, gam, bet = groups[i][0], groups[i][1], groups[i][2]
             last = i == units - 1
             dy, dg, db, g = _bn_bwd(dz, ys[i], zs[i], gam, cs[i], True, last, beta=bet,
-                                    has_res=last)
+                                    has_res=last, partial=fused,
+                                    premasked=last and grad_premasked)
             if last:
                 g_short = g
             inp = zs[i - 1] if i > 0 else x
             dw = _conv_wgrad(dy, inp, w, strides[i], pads[i])
             put(i, dw, dg, db)
             if i > 0:
-                dz = _conv_dgrad(dy, w, inp.shape, strides[i], pads[i])
+                if _FUSE_BN_REDUCE["on"]:
+                    dz, fused = _conv_dgrad_bn(dy, w, inp.shape, strides[i], pads[i], ys[i - 1],
+                                               cs[i - 1][2:4])
+                else:
+                    dz, fused = _conv_dgrad(dy, w, inp.shape, strides[i], pads[i]), None
             else:
                 addend, sub2 = g_short, False
                 if has_ds:
@@ -545,7 +575,7 @@ class ResidualBlockFn(Function):
                             addend = _conv_dgrad(dyd, wd, x.shape, ds_stride, 0)
                 if ctx.needs_input_grad[0]:
                     grads[0] = _conv_dgrad(dy, w, x.shape, strides[i], pads[i], addend=addend,
-                                           addend_sub2=sub2)
+                                           addend_sub2=sub2, mask_src=x if premask_in else None)
         return tuple(grads)
 
 
@@ -554,9 +584,19 @@ def residual_block_supported(convs):
                bn_supported(w.shape[0]) and _krsc_ok(w) for w in convs)
 
 
-def residual_block(x, units, downsample, training, momentum, eps):
+_FUSE_BN_REDUCE = {"on": True}
+
+
+def residual_block(x, units, downsample, training, momentum, eps, premask_in=False,
+                   grad_premasked=False):
     """``units``: list of (weight, stride, padding, gamma, beta, running_mean, running_var);
-    ``downsample``: None or (weight, stride, gamma, beta, running_mean, running_var)."""
+    ``downsample``: None or (weight, stride, gamma, beta, running_mean, running_var).
+
+    ``premask_in`` / ``grad_premasked`` are the contract of :func:`residual_chain` (never set them
+    by hand): the block's input is the ReLU output of the previous fused block, so this block
+    returns its input gradient already multiplied by that ReLU's mask, and the previous block is
+    told that the gradient it receives is pre-masked (its last BatchNorm backward then reads
+    neither the activation nor writes a masked copy)."""
     tensors, strides, pads = [], [], []
     for (w, s, p, g, b, rm, rv) in units:
         tensors += [w, g, b, rm, rv]
@@ -567,8 +607,21 @@ def residual_block(x, units, downsample, training, momentum, eps):
         w, ds_stride, g, b, rm, rv = downsample
         tensors += [w, g, b, rm, rv]
     cfg = (len(units), tuple(strides), tuple(pads), downsample is not None, ds_stride,
-           bool(training), float(momentum), float(eps))
+           bool(training), float(momentum), float(eps), bool(premask_in), bool(grad_premasked))
     return ResidualBlockFn.apply(x, cfg, *tensors)
+
+
+def residual_chain(x, blocks, training, momentum, eps):
+    """Run consecutive residual blocks (``blocks`` = list of (units, downsample) as for
+    :func:`residual_block`) whose intermediate activations have no other consumer.  Each block
+    is still one autograd node; adjacent nodes exchange ReLU-masked gradients (see
+    :func:`residual_block`), which removes two full tensor passes per block boundary."""
+    n = len(blocks)
+    chain = bool(training) and torch.is_grad_enabled()
+    for i, (units, ds) in enumerate(blocks):
+        x = residual_block(x, units, ds, training, momentum, eps,
+                           premask_in=chain and i > 0, grad_premasked=chain and i < n - 1)
+    return x
 
 
 def set_direct_grads(on: bool):

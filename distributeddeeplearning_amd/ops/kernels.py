@@ -156,18 +156,37 @@ def storage_numel_from(x):
 
 
 def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil, Hout, Wout,
-               addend=None, stats=None, addend_sub2=False):
-    """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel)."""
+               addend=None, stats=None, addend_sub2=False, ep_y=None, ep_fcoef=None, ep_mask=None):
+    """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel).
+
+    Fused backward epilogues: ``ep_y`` + ``ep_fcoef`` (+ ``stats``) store the gradient masked by
+    the ReLU of ``bn(ep_y)`` and emit the BatchNorm-backward partial sums per tile; ``ep_mask``
+    zeroes the result where that tensor is <= 0."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
-    check(lib().ddl_conv_igemm(ptr(x_ptr_tensor), ptr(w), ptr(y), ptr(addend), ptr(stats),
-                               _i64(xn), _i64(w.numel()), _i32(B), _i32(Hin), _i32(Win), _i32(C),
-                               _i64(sb), _i64(sh), _i64(sw), _i32(Hout), _i32(Wout), _i32(n_out),
-                               _i32(R), _i32(S), _i32(ostride), _i32(pad), _i32(pad_w), _i32(idil),
-                               _i32(bool(addend_sub2)), stream()), "conv_igemm")
+    for t in (ep_y, ep_mask):
+        if t is not None and t.numel() != y.numel():
+            raise KernelError("conv_igemm: epilogue tensor does not match the output shape")
+    if ep_fcoef is not None and (ep_fcoef.numel() != 2 * n_out or not ep_fcoef.is_contiguous()):
+        raise KernelError("conv_igemm: ep_fcoef must be a contiguous [2, N] tensor")
+    if ep_y is not None:
+        need = conv_tiles_m_bwd(y.numel() // n_out, Hout, Wout, idil, ostride) * 2 * n_out
+        if stats is None or stats.numel() < need:
+            raise KernelError("conv_igemm: partial buffer too small for the fused reduce")
+    check(lib().ddl_conv_igemm_ex(ptr(x_ptr_tensor), ptr(w), ptr(y), ptr(addend), ptr(stats),
+                                  _i64(xn), _i64(w.numel()), _i32(B), _i32(Hin), _i32(Win), _i32(C),
+                                  _i64(sb), _i64(sh), _i64(sw), _i32(Hout), _i32(Wout), _i32(n_out),
+                                  _i32(R), _i32(S), _i32(ostride), _i32(pad), _i32(pad_w),
+                                  _i32(idil), _i32(bool(addend_sub2)), ptr(ep_y), ptr(ep_fcoef),
+                                  ptr(ep_mask), stream()), "conv_igemm")
 
 
 def conv_tiles_m(M):
     return int(lib().ddl_conv_igemm_tiles_m(_i64(M)))
+
+
+def conv_tiles_m_bwd(M, Hout, Wout, idil, ostride):
+    return int(lib().ddl_conv_igemm_tiles_m_bwd(_i64(M), _i32(Hout), _i32(Wout), _i32(idil),
+                                                _i32(ostride)))
 
 
 def conv_wgrad_splits(M, K, C, R, S):
@@ -225,9 +244,13 @@ def bn_bwd_reduce(dz, y, z, fcoef, partial, M, C, mask, G):
 
 
 def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef, accumulate=False):
+    work = None
+    if G > 256:
+        P = int(lib().ddl_bn_fold_slices(_i32(G)))
+        work = torch.empty((P, 2, C), dtype=torch.float32, device=partial.device)
     check(lib().ddl_bn_bwd_finalize(ptr(partial), _i32(G), _i32(C), _i64(M), ptr(gamma), ptr(mean),
                                     ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(coef),
-                                    _i32(bool(accumulate)), stream()), "bn_bwd_finalize")
+                                    _i32(bool(accumulate)), ptr(work), stream()), "bn_bwd_finalize")
 
 
 def bn_bwd_apply(dz, y, z, fcoef, coef, dy, gout, M, C, mask):

@@ -275,6 +275,94 @@ def test_bottleneck_block_matches_fp32_reference():
         ok(g_hip[n], g_at[n], g_ref[n], n)
 
 
+@pytest.mark.parametrize("case", [(4, 128, 28, 28, 128, 3, 1, 1), (3, 128, 28, 28, 128, 3, 2, 1),
+                                  (5, 64, 14, 14, 256, 1, 1, 0), (2, 64, 15, 15, 64, 3, 2, 1)])
+def test_dgrad_fused_bn_reduce_and_relu_mask_epilogues(case):
+    """EPI 2 (masked gradient + BatchNorm-backward partial sums) and EPI 3 (ReLU pre-mask) of the
+    backward-data kernel against the unfused kernel followed by plain tensor math."""
+    hip = _hip()
+    hip.reset_caches()
+    B, Cin, H, W, Cout, k, stride, pad = case
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    w = (torch.randn((Cout, Cin, k, k), device=DEV) / math.sqrt(Cin * k * k)).to(BF)
+    w = w.contiguous(memory_format=CL)
+    dy = rand_nhwc(B, Cout, Ho, Wo, seed=31)
+    yprev = rand_nhwc(B, Cin, H, W, seed=32)
+    fco = torch.stack([torch.rand(Cin, device=DEV) + 0.5, torch.randn(Cin, device=DEV) * 0.3])
+    dx = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad)
+    g, partial = hip._conv_dgrad_bn(dy, w, (B, Cin, H, W), stride, pad, yprev, fco)
+    on = torch.addcmul(fco[1].view(1, -1, 1, 1), yprev.float(), fco[0].view(1, -1, 1, 1)) > 0
+    g_ref = torch.where(on, dx.float(), torch.zeros((), device=DEV))
+    # the mask is recomputed with one fused multiply-add in both places: only elements whose
+    # pre-activation rounds to exactly zero may differ
+    mism = (g.float() != g_ref).float().mean()
+    assert float(mism) < 1e-4
+    s = partial.sum(0)
+    gf = g.float()
+    s1 = gf.sum(dim=(0, 2, 3))
+    s2 = (gf * yprev.float()).sum(dim=(0, 2, 3))
+    assert torch.allclose(s[0], s1, rtol=1e-3, atol=1e-3 * float(s1.abs().max()))
+    assert torch.allclose(s[1], s2, rtol=1e-3, atol=1e-3 * float(s2.abs().max()))
+    z = torch.relu(rand_nhwc(B, Cin, H, W, seed=33))
+    add = rand_nhwc(B, Cin, H, W, seed=34)
+    for addend in (None, add):
+        if k == 1 and stride == 2 and addend is None:
+            continue
+        base = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad, addend=addend)
+        masked = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad, addend=addend, mask_src=z)
+        assert torch.equal(masked, torch.where(z > 0, base, torch.zeros_like(base)))
+
+
+def test_residual_chain_matches_unchained_blocks():
+    """``ops.residual_chain`` (ReLU-masked gradients handed between fused block nodes, BatchNorm
+    reduce in the dgrad epilogue) against the same blocks run one by one without either fusion."""
+    from distributeddeeplearning_amd.models.resnet import Bottleneck, _block_spec
+    from distributeddeeplearning_amd.ops import functional as ops
+
+    hip = _hip()
+    hip.reset_caches()
+
+    def make():
+        torch.manual_seed(7)
+        ms = [Bottleneck(128, 64, 2, True, False), Bottleneck(256, 64, 1, False, False),
+              Bottleneck(256, 64, 1, False, False)]
+        for m in ms:
+            m.to(DEV).train()
+            for mod in m.modules():
+                if hasattr(mod, "kernel"):
+                    mod.weight.data = mod.weight.data.to(BF).contiguous(memory_format=CL)
+        return ms
+
+    x0 = torch.relu(rand_nhwc(6, 128, 28, 28, seed=41))
+    gout = rand_nhwc(6, 256, 14, 14, seed=42)
+
+    def run(chained):
+        ms = make()
+        x = x0.detach().clone().requires_grad_(True)
+        hip._FUSE_BN_REDUCE["on"] = chained
+        try:
+            if chained:
+                specs = [_block_spec(m.pairs(), m.downsample) for m in ms]
+                out = ops.residual_chain(x, specs, True, 0.1, 1e-5)
+            else:
+                out = x
+                for m in ms:
+                    out = m(out)
+            out.backward(gout)
+        finally:
+            hip._FUSE_BN_REDUCE["on"] = True
+        return out.detach(), x.grad, [p.grad for m in ms for p in m.parameters()]
+
+    o_a, dx_a, g_a = run(False)
+    o_b, dx_b, g_b = run(True)
+    assert torch.equal(o_a, o_b)
+    # identical math up to the summation order of the BatchNorm partials (bf16 re-rounding of
+    # dy then propagates): compare in rms
+    assert rms_relerr(dx_b, dx_a) < 1e-2
+    for a, b in zip(g_a, g_b):
+        assert rms_relerr(b, a) < 1e-2
+
+
 def test_residual_block_direct_grads_match_autograd_accumulation():
     """Fused block writing into pre-existing ``param.grad`` arena views (direct mode) must give
     the same gradients as returning them to autograd, and must notify the listeners once per
