@@ -99,6 +99,7 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
         if engine not in ("torch", "native"):
             raise ValueError("unknown HVD_ENGINE %r (expected torch|native)" % engine)
         _S.engine = engine
+        force = bool(cfg.force_collectives)
         if world > 1 and engine == "native":
             from .comm import NativeComm
 
@@ -108,7 +109,7 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
                                  timeout_s or cfg.collective_timeout_s, cfg.stall_warning_s,
                                  use_rccl=(want == "rccl"), timeline=cfg.timeline)
             _S.backend = want
-        elif world > 1:
+        elif world > 1 or force:
             if dist.is_initialized():
                 _S.group = dist.group.WORLD
                 _S.owns_default_group = False
@@ -144,7 +145,7 @@ def shutdown() -> None:
                 _S.comm.shutdown()
             except Exception:  # pragma: no cover - teardown best effort
                 pass
-        if _S.size > 1 and _S.owns_default_group and dist.is_initialized():
+        if _S.comm is not None and _S.owns_default_group and dist.is_initialized():
             try:
                 dist.destroy_process_group()
             except Exception:  # pragma: no cover - teardown best effort

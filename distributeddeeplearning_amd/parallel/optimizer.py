@@ -131,8 +131,7 @@ class _DistributedMixin:
 
     def _ddl_launch(self, st):
         st.launched = True
-        world = _b.size()
-        if world == 1:
+        if _b.size() == 1 and _b.comm() is None:
             return
         name = "grad.%s.bucket%d" % (str(st.dtype).replace("torch.", ""), st.bucket.index)
         _tl.begin(name, "ALLREDUCE")

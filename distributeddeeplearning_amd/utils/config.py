@@ -164,6 +164,8 @@ class EngineConfig:
     stall_warning_s: float = 60.0  # Horovod's stall-check default [EXT]
     fault_inject: Optional[str] = None  # "rank:step"
     cycle_time_ms: float = 0.0  # accepted for Horovod compat; static buckets need no cycle
+    # run the gradient exchange even with one rank (rehearses the RCCL path on a one-GPU box)
+    force_collectives: bool = False
 
     @classmethod
     def from_env(cls) -> "EngineConfig":
@@ -181,4 +183,5 @@ class EngineConfig:
                                       "HOROVOD_STALL_CHECK_TIME_SECONDS"),
             fault_inject=env_str("HVD_FAULT_INJECT", None),
             cycle_time_ms=env_float("HVD_CYCLE_TIME", 0.0, "HOROVOD_CYCLE_TIME"),
+            force_collectives=env_bool("HVD_FORCE_COLLECTIVES", False),
         )

@@ -549,3 +549,26 @@ def test_nchw_to_nhwc_normalize():
     u8 = (x * 255).to(torch.uint8)
     out8 = kernels.nchw_to_nhwc_normalize(u8, mean, sd, in_scale=1.0 / 255)
     assert torch.allclose(out8.float(), ref, atol=3e-2)
+
+
+def test_bench_step_with_forced_rccl_collectives():
+    """The whole distributed step (arena views, direct gradient writes, bucket launch from the
+    listeners, RCCL all-reduce on its stream, event-ordered fused update) with a one-rank RCCL
+    communicator (``HVD_FORCE_COLLECTIVES=1``): what the driver's N>1 runs execute, minus peers."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HVD_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               HVD_DEBUG="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup",
+                          "2", "--batch", "32", "--image", "96"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["ops_backend"] == "hip"
+    assert math.isfinite(rec["final_loss"]) and rec["final_loss"] < 12.0
