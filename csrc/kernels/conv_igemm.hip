@@ -60,10 +60,11 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 //      2 backward-data feeding a BatchNorm+ReLU backward: g = dz * relu'(bn(y)) is stored and the
 //        tile's sum g / sum g*y partials are emitted (replaces the separate K8a reduce pass);
 //      3 backward-data whose consumer is a ReLU: store dz * (mask > 0) so that the consumer's
-//        backward needs neither the mask tensor nor a masked copy of the gradient.
+//        backward needs neither the mask tensor nor a masked copy of the gradient;
+//      4 = 3 plus the sum g / sum g*y partials of the BatchNorm that feeds that ReLU (ep_y).
 template <int BM, int BN, int BK, int EPI, bool ADDEND>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p) {
-    constexpr bool STATS = EPI == 1 || EPI == 2;
+    constexpr bool STATS = EPI == 1 || EPI == 2 || EPI == 4;
     constexpr int CPR = BK / 8;            // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;         // rows covered per pass of the 256 threads
     constexpr int A_LOADS = BM / RPP, B_LOADS = BN / RPP;
@@ -271,10 +272,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
                     for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(a[e]));
                 }
             }
-            if (EPI == 3) {
+            if (EPI == 3 || EPI == 4) {
                 bf16x8 zm = *reinterpret_cast<const bf16x8*>(p.ep_mask + o);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = bf2f(zm[e]) > 0.f ? v[e] : f2bf(0.f);
+            }
+            if (EPI == 4) {
+                bf16x8 yv = *reinterpret_cast<const bf16x8*>(p.ep_y + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float g = bf2f(v[e]); s1[e] += g; s2[e] += g * bf2f(yv[e]); }
             }
             if (EPI == 2) {
                 bf16x8 yv = *reinterpret_cast<const bf16x8*>(p.ep_y + o);
@@ -322,8 +328,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 template <int BM, int BN, int BK>
 int launch_cfg(const IGemmParams& p, hipStream_t stream) {
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
-    if (p.stats && p.addend) return DDL_EINVAL;
-    if (p.ep_y) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 2, false>), grid, block, 0, stream, p);
+    if (p.stats && p.addend && !(p.ep_y && p.ep_mask)) return DDL_EINVAL;
+    if (p.ep_y && p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, true>), grid, block, 0, stream, p);
+    else if (p.ep_y && p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, false>), grid, block, 0, stream, p);
+    else if (p.ep_y) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 2, false>), grid, block, 0, stream, p);
     else if (p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, true>), grid, block, 0, stream, p);
     else if (p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, false>), grid, block, 0, stream, p);
     else if (p.stats) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 1, false>), grid, block, 0, stream, p);
@@ -362,8 +370,10 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
     if (!ddl_aligned16(x) || !ddl_aligned16(w) || !ddl_aligned16(y) || (addend && !ddl_aligned16(addend))) return DDL_EALIGN;
     if ((ep_y && !ddl_aligned16(ep_y)) || (ep_fcoef && !ddl_aligned16(ep_fcoef)) || (ep_mask && !ddl_aligned16(ep_mask))) return DDL_EALIGN;
     // fused BatchNorm-backward reduce needs y, the forward coefficients and the partial buffer together
-    if ((ep_y != nullptr) != (ep_fcoef != nullptr) || (ep_y && (!stats || addend || ep_mask))) return DDL_EINVAL;
-    if (ep_mask && stats) return DDL_EINVAL;
+    // (EPI 2: ep_y + ep_fcoef, no addend; EPI 4: ep_y + ep_mask, addend allowed)
+    if (ep_fcoef && (!ep_y || ep_mask || addend)) return DDL_EINVAL;
+    if (ep_y && (!stats || (ep_fcoef == nullptr) == (ep_mask == nullptr))) return DDL_EINVAL;
+    if (ep_mask && stats && !ep_y) return DDL_EINVAL;
     if ((xs_b % 8) || (xs_h % 8)) return DDL_EALIGN;
     // every tap address must be 16-byte aligned: either pixels are >= 8 elements apart, or (S == 1,
     // undilated) only multiples of ostride are visited and those are

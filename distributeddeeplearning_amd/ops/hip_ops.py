@@ -203,9 +203,12 @@ def _conv_fwd(x, w, stride, padding, want_stats):
     return y, stats
 
 
-def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False, mask_src=None):
+def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False, mask_src=None,
+                bn_y=None):
     """dx of a convolution; ``addend`` is summed in the epilogue (shortcut gradient) and
-    ``mask_src`` (the ReLU output that IS the conv input) zeroes dx where it is <= 0."""
+    ``mask_src`` (the ReLU output that IS the conv input) zeroes dx where it is <= 0.  With
+    ``bn_y`` (the pre-BatchNorm tensor behind that ReLU; needs ``mask_src``) the kernel also
+    emits that BatchNorm's backward partial sums and ``(dx, partial)`` is returned."""
     B, C, H, W = x_shape
     _, _, R, S = w.shape
     wt = _WT.get(w)
@@ -217,9 +220,14 @@ def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False,
         dx[:, :, ::2, ::2] = _conv_dgrad_1x1s2_compact(dy, w)
         return dx
     dx = _empty_nhwc(B, C, H, W, dy.device)
+    partial = None
+    if bn_y is not None:
+        T = K.conv_tiles_m_bwd(B * H * W, H, W, stride, 1)
+        partial = torch.empty((T, 2, C), dtype=torch.float32, device=dy.device)
     K.conv_igemm(dy, _geom(dy), wt, dx, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
-                 addend=addend, addend_sub2=addend_sub2, ep_mask=mask_src)
-    return dx
+                 addend=addend, addend_sub2=addend_sub2, ep_mask=mask_src, ep_y=bn_y,
+                 stats=partial)
+    return dx if bn_y is None else (dx, partial)
 
 
 def _conv_dgrad_bn(dy, w, x_shape, stride, padding, y_prev, fcoef_prev):
@@ -512,6 +520,8 @@ class ResidualBlockFn(Function):
             saved_z.append(z)
             saved_c.append(c)
             cur = z
+        if len(cfg) > 11 and cfg[11] is not None:
+            cfg[11].y = saved_y[-1]
         ctx.cfg = cfg
         ctx.n_in = 2 + len(tensors)
         ctx.params = groups  # parameters/buffers are leaves: plain references are safe
@@ -525,6 +535,7 @@ class ResidualBlockFn(Function):
     def backward(ctx, dout):
         units, strides, pads, has_ds, ds_stride, training, momentum, eps = ctx.cfg[:8]
         premask_in, grad_premasked = ctx.cfg[8], ctx.cfg[9]
+        link_in, link_out = (ctx.cfg[10], ctx.cfg[11]) if len(ctx.cfg) > 11 else (None, None)
         if not training:
             raise K.KernelError("fused residual block: backward in eval mode is not supported")
         saved = ctx.saved_tensors
@@ -542,7 +553,11 @@ class ResidualBlockFn(Function):
 
         dz = dout
         g_short = None
-        fused = None  # BatchNorm-backward partials produced by the previous dgrad's epilogue
+        # BatchNorm-backward partials produced by the previous dgrad's epilogue (for the last
+        # unit: by the NEXT block's input-gradient kernel, handed over through the chain link)
+        fused = None
+        if grad_premasked and link_out is not None:
+            fused, link_out.partial = link_out.partial, None
         for i in range(units - 1, -1, -1):
             w, gam, bet = groups[i][0], groups[i][1], groups[i][2]
             last = i == units - 1
@@ -574,8 +589,17 @@ class ResidualBlockFn(Function):
                         else:
                             addend = _conv_dgrad(dyd, wd, x.shape, ds_stride, 0)
                 if ctx.needs_input_grad[0]:
-                    grads[0] = _conv_dgrad(dy, w, x.shape, strides[i], pads[i], addend=addend,
-                                           addend_sub2=sub2, mask_src=x if premask_in else None)
+                    bn_y = link_in.y if (premask_in and link_in is not None and
+                                         _FUSE_BN_REDUCE["on"]) else None
+                    if bn_y is not None and bn_y.shape != x.shape:
+                        bn_y = None
+                    res = _conv_dgrad(dy, w, x.shape, strides[i], pads[i], addend=addend,
+                                      addend_sub2=sub2, mask_src=x if premask_in else None,
+                                      bn_y=bn_y)
+                    if bn_y is not None:
+                        grads[0], link_in.partial = res
+                    else:
+                        grads[0] = res
         return tuple(grads)
 
 
@@ -587,8 +611,20 @@ def residual_block_supported(convs):
 _FUSE_BN_REDUCE = {"on": True}
 
 
+class _ChainLink:
+    """Hand-over between two adjacent fused blocks of a chain: the earlier block leaves the
+    pre-BatchNorm output of its last unit (``y``) for the later block, whose backward returns
+    the BatchNorm-backward partial sums (``partial``) computed in its input-gradient epilogue."""
+
+    __slots__ = ("y", "partial")
+
+    def __init__(self):
+        self.y = None
+        self.partial = None
+
+
 def residual_block(x, units, downsample, training, momentum, eps, premask_in=False,
-                   grad_premasked=False):
+                   grad_premasked=False, link_in=None, link_out=None):
     """``units``: list of (weight, stride, padding, gamma, beta, running_mean, running_var);
     ``downsample``: None or (weight, stride, gamma, beta, running_mean, running_var).
 
@@ -607,7 +643,8 @@ def residual_block(x, units, downsample, training, momentum, eps, premask_in=Fal
         w, ds_stride, g, b, rm, rv = downsample
         tensors += [w, g, b, rm, rv]
     cfg = (len(units), tuple(strides), tuple(pads), downsample is not None, ds_stride,
-           bool(training), float(momentum), float(eps), bool(premask_in), bool(grad_premasked))
+           bool(training), float(momentum), float(eps), bool(premask_in), bool(grad_premasked),
+           link_in, link_out)
     return ResidualBlockFn.apply(x, cfg, *tensors)
 
 
@@ -618,9 +655,12 @@ def residual_chain(x, blocks, training, momentum, eps):
     :func:`residual_block`), which removes two full tensor passes per block boundary."""
     n = len(blocks)
     chain = bool(training) and torch.is_grad_enabled()
+    links = [_ChainLink() for _ in range(n - 1)] if chain else []
     for i, (units, ds) in enumerate(blocks):
         x = residual_block(x, units, ds, training, momentum, eps,
-                           premask_in=chain and i > 0, grad_premasked=chain and i < n - 1)
+                           premask_in=chain and i > 0, grad_premasked=chain and i < n - 1,
+                           link_in=links[i - 1] if chain and i > 0 else None,
+                           link_out=links[i] if chain and i < n - 1 else None)
     return x
 
 

@@ -311,6 +311,14 @@ def test_dgrad_fused_bn_reduce_and_relu_mask_epilogues(case):
         base = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad, addend=addend)
         masked = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad, addend=addend, mask_src=z)
         assert torch.equal(masked, torch.where(z > 0, base, torch.zeros_like(base)))
+        both, part = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad, addend=addend, mask_src=z,
+                                     bn_y=yprev)
+        assert torch.equal(both, masked)
+        t1 = masked.float().sum(dim=(0, 2, 3))
+        t2 = (masked.float() * yprev.float()).sum(dim=(0, 2, 3))
+        ps = part.sum(0)
+        assert torch.allclose(ps[0], t1, rtol=1e-3, atol=1e-3 * float(t1.abs().max()))
+        assert torch.allclose(ps[1], t2, rtol=1e-3, atol=1e-3 * float(t2.abs().max()))
 
 
 def test_residual_chain_matches_unchained_blocks():
