@@ -15,6 +15,7 @@
 // fp32 partial slab and `ddl_splitk_reduce` sums the slabs in a fixed order (deterministic,
 // no float atomics) into the gradient arena in bf16 or fp32.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -46,8 +47,8 @@ __device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r)
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
-template <int BMw, int BNw>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
+template <int BMw, int BNw, bool SIMPLE>
+__global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p) {
     constexpr int BK = 32;                          // reduction rows per tile
     constexpr int A_STR = BMw * 2 + 32, B_STR = BNw * 2 + 32;  // padded row strides (bytes)
     constexpr int A_BYTES = BK * A_STR, B_BYTES = BK * B_STR;
@@ -83,37 +84,70 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
     const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
 
+    // Per-thread load slots are fixed over the whole reduction: (row, chunk) never change and the
+    // pixel index only advances by BK per tile.  dy offsets therefore ride in the buffer
+    // instruction's scalar offset; the (b, ho, wo) decomposition of the x row is computed once
+    // and then stepped (no divisions and no 64-bit arithmetic in the loop).
     const int hw = p.Hout * p.Wout;
     u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
-    auto fetch = [&](int kt) {
-        const int mb = m_begin + kt * BK;
+    unsigned a_voff[A_LOADS];
+    int a_row[A_LOADS];
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            int idx = tid + i * 256;
-            int row = idx / A_CPR, ch = idx - row * A_CPR;
-            int m = mb + row, n = n0 + ch * 8;
-            bool ok = (row < BK) & (m < m_end) & (n < p.K);
-            long long e = (long long)m * p.K + n;
-            a_reg[i] = wg_load16(dyr, ok ? (unsigned)(e * 2) : 0x80000000u);
+    for (int i = 0; i < A_LOADS; ++i) {
+        int idx = tid + i * 256;
+        int row = idx / A_CPR, ch = idx - row * A_CPR;
+        int n = n0 + ch * 8;
+        a_row[i] = (row < BK && n < p.K) ? row : (1 << 30);  // never < rows_left
+        a_voff[i] = ((unsigned)(m_begin + row) * (unsigned)p.K + (unsigned)n) * 2u;
+    }
+    int b_row[B_LOADS], b_wo[B_LOADS], b_ho[B_LOADS];
+    unsigned b_base[B_LOADS];  // byte offset of (b, hi = ho*stride - pad + r, wi = 0, c)
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        int idx = tid + i * 256;
+        int row = idx / B_CPR, ch = idx - row * B_CPR;
+        int c = c0 + ch * 8;
+        b_row[i] = (row < BK && c < p.C) ? row : (1 << 30);
+        int m = m_begin + row;
+        if (SIMPLE) {
+            b_base[i] = ((unsigned)m * (unsigned)p.xs_w + (unsigned)c) * 2u;
+            b_wo[i] = 0; b_ho[i] = 0;
+        } else {
+            int b, rem, ho, wo;
+            fdivmod(m, hw, p.inv_hw, b, rem);
+            fdivmod(rem, p.Wout, p.inv_w, ho, wo);
+            b_wo[i] = wo; b_ho[i] = ho;
+            b_base[i] = (unsigned)((b * (int)p.xs_b + (ho * p.stride - p.pad + frr) * (int)p.xs_h + c) * 2);
         }
+    }
+    const int step_w = BK % p.Wout, step_h = BK / p.Wout;         // BK pixels = step_h rows + step_w
+    const int xs_w2 = (int)p.xs_w * 2;
+    const int row_bytes = p.stride * (int)p.xs_h * 2;              // one output row down, in x bytes
+    const int img_bytes = (int)p.xs_b * 2 - p.Hout * row_bytes;    // wrap to the next image
+    auto fetch = [&](int kt) {
+        const int rows_left = m_end - (m_begin + kt * BK);
+        const int a_soff = kt * (BK * 2) * p.K;
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            int idx = tid + i * 256;
-            int row = idx / B_CPR, ch = idx - row * B_CPR;
-            int m = mb + row, c = c0 + ch * 8;
-            bool ok = (row < BK) & (m < m_end) & (c < p.C);
-            long long e;
-            if (p.simple) {
-                e = (long long)m * p.xs_w + c;
-            } else {
-                int b, rem, ho, wo;
-                fdivmod(m, hw, p.inv_hw, b, rem);
-                fdivmod(rem, p.Wout, p.inv_w, ho, wo);
-                int hi = ho * p.stride - p.pad + frr, wi = wo * p.stride - p.pad_w + fs;
-                ok = ok & (hi >= 0) & (hi < p.Hin) & (wi >= 0) & (wi < p.Win);
-                e = (long long)b * p.xs_b + (long long)hi * p.xs_h + (long long)wi * p.xs_w + c;
+        for (int i = 0; i < A_LOADS; ++i)
+            a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyr, (int)(a_row[i] < rows_left ? a_voff[i] : 0x80000000u), a_soff, 0);
+        if (SIMPLE) {
+            const int b_soff = kt * BK * xs_w2;
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i)
+                b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(b_row[i] < rows_left ? b_base[i] : 0x80000000u), b_soff, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                int hi = b_ho[i] * p.stride - p.pad + frr, wi = b_wo[i] * p.stride - p.pad_w + fs;
+                bool ok = (b_row[i] < rows_left) & (hi >= 0) & (hi < p.Hin) & (wi >= 0) & (wi < p.Win);
+                b_reg[i] = wg_load16(xr, ok ? b_base[i] + (unsigned)(wi * xs_w2) : 0x80000000u);
+                // advance this slot by BK pixels
+                int wo = b_wo[i] + step_w, ho = b_ho[i] + step_h;
+                unsigned base = b_base[i] + (unsigned)(step_h * row_bytes);
+                if (wo >= p.Wout) { wo -= p.Wout; ++ho; base += (unsigned)row_bytes; }
+                while (ho >= p.Hout) { ho -= p.Hout; base += (unsigned)img_bytes; }
+                b_wo[i] = wo; b_ho[i] = ho; b_base[i] = base;
             }
-            b_reg[i] = wg_load16(xr, ok ? (unsigned)(e * 2) : 0x80000000u);
         }
     };
     auto stash = [&](int stage) {
@@ -243,7 +277,8 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
     p.tiles_k = (p.K + BMw - 1) / BMw;
     p.tiles_c = (p.C + BNw - 1) / BNw;
     dim3 grid(p.tiles_k * p.tiles_c * p.R * p.S * p.splits), block(256);
-    hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw>), grid, block, 0, stream, p);
+    if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false>), grid, block, 0, stream, p);
     return ddl_launch_status();
 }
 
@@ -254,7 +289,17 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
 extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S) {
     int bm = K <= 64 ? 64 : 128, bn = C <= 32 ? 32 : (C <= 64 ? 64 : 128);
     long long tiles = (long long)((K + bm - 1) / bm) * ((C + bn - 1) / bn) * R * S;
-    long long want = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
+    // Workgroups to aim for, from the DDL_WGRAD_TARGET sweep of benchmarks/kernel_bench.py on
+    // MI355X (profiles/r1_notes.md): every workgroup costs one fp32 tile of partial-sum traffic
+    // (64 KB for 128x128), so the 1x1 GEMMs want just 2 per CU; 3x3 taps re-read their operands
+    // through L2 and want more parallelism, the 64-channel 3x3 (tiny tiles) the most.
+    static const int forced = getenv("DDL_WGRAD_TARGET") ? atoi(getenv("DDL_WGRAD_TARGET")) : 0;  // tuning knob
+    int target;
+    if (R * S == 1) target = (K <= 64 || C <= 64) ? 768 : 512;
+    else if (R * S >= 9) target = (C <= 64) ? 3072 : 896;
+    else target = 1024;
+    if (forced > 0) target = forced;
+    long long want = (target + tiles - 1) / tiles;
     long long max_by_m = (M + 255) / 256;                  // at least 256 reduction rows per split
     if (want > max_by_m) want = max_by_m;
     if (want < 1) want = 1;
