@@ -28,7 +28,7 @@ struct WgradParams {
     long long xs_b, xs_h, xs_w;
     int Hout, Wout, K, M;
     int R, S, stride, pad, pad_w;
-    int tiles_k, tiles_c, splits, m_per_split;
+    int tiles_k, tiles_rsc, splits, m_per_split;  // tiles over K and over the flattened (r, s, c) axis
     int simple;  // x row of pixel m is x + m*xs_w (1x1, stride 1, no padding)
     float inv_hw, inv_w;
 };
@@ -47,7 +47,7 @@ __device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r)
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
-template <int BMw, int BNw, bool SIMPLE>
+template <int BMw, int BNw, bool SIMPLE, bool UNITAP>
 __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p) {
     constexpr int BK = 32;                          // reduction rows per tile
     constexpr int A_STR = BMw * 2 + 32, B_STR = BNw * 2 + 32;  // padded row strides (bytes)
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
 
-    const int ntile = p.tiles_k * p.R * p.S * p.tiles_c;
+    const int ntile = p.tiles_k * p.tiles_rsc;
     const int nwg = ntile * p.splits;
     int bid = blockIdx.x;
     {
@@ -71,10 +71,13 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     }
     const int split = bid / ntile;
     int t = bid - split * ntile;
-    const int tile_k = t % p.tiles_k; t /= p.tiles_k;
-    const int tile_c = t % p.tiles_c; t /= p.tiles_c;
-    const int fs = t % p.S, frr = t / p.S;
-    const int n0 = tile_k * BMw, c0 = tile_c * BNw;
+    const int tile_k = t % p.tiles_k;
+    const int tile_j = t / p.tiles_k;
+    // columns of the tile = BNw consecutive entries of the flattened (r, s, c) axis: whole taps
+    // when C divides BNw (several taps per tile: the dy tile is loaded once for all of them), a
+    // channel slice of one tap when BNw divides C
+    const int n0 = tile_k * BMw, j0 = tile_j * BNw;
+    const int RSC = p.R * p.S * p.C;
 
     const int m_begin = split * p.m_per_split;
     int m_end = m_begin + p.m_per_split;
@@ -90,34 +93,39 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     // and then stepped (no divisions and no 64-bit arithmetic in the loop).
     const int hw = p.Hout * p.Wout;
     u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    constexpr unsigned INVALID = 0x80000000u;
     unsigned a_voff[A_LOADS];
-    int a_row[A_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         int idx = tid + i * 256;
         int row = idx / A_CPR, ch = idx - row * A_CPR;
         int n = n0 + ch * 8;
-        a_row[i] = (row < BK && n < p.K) ? row : (1 << 30);  // never < rows_left
-        a_voff[i] = ((unsigned)(m_begin + row) * (unsigned)p.K + (unsigned)n) * 2u;
+        a_voff[i] = (row < BK && n < p.K) ? ((unsigned)(m_begin + row) * (unsigned)p.K + (unsigned)n) * 2u : INVALID;
     }
-    int b_row[B_LOADS], b_wo[B_LOADS], b_ho[B_LOADS];
+    int b_wo[B_LOADS], b_ho[B_LOADS], b_dh[B_LOADS], b_dw[B_LOADS];
     unsigned b_base[B_LOADS];  // byte offset of (b, hi = ho*stride - pad + r, wi = 0, c)
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         int idx = tid + i * 256;
         int row = idx / B_CPR, ch = idx - row * B_CPR;
-        int c = c0 + ch * 8;
-        b_row[i] = (row < BK && c < p.C) ? row : (1 << 30);
+        int j = j0 + ch * 8;                      // flattened (r, s, c) index of this 8-channel chunk
+        // UNITAP (C is a multiple of BNw): the whole tile belongs to one filter tap
+        int tap = (UNITAP ? j0 : j) / p.C, c = j - tap * p.C;
+        int fr = tap / p.S, fs = tap - fr * p.S;
+        const bool live = row < BK && j < RSC;
+        b_dh[i] = fr - p.pad;
+        b_dw[i] = fs - p.pad_w;
         int m = m_begin + row;
         if (SIMPLE) {
-            b_base[i] = ((unsigned)m * (unsigned)p.xs_w + (unsigned)c) * 2u;
+            b_base[i] = live ? ((unsigned)m * (unsigned)p.xs_w + (unsigned)c) * 2u : INVALID;
             b_wo[i] = 0; b_ho[i] = 0;
         } else {
             int b, rem, ho, wo;
             fdivmod(m, hw, p.inv_hw, b, rem);
             fdivmod(rem, p.Wout, p.inv_w, ho, wo);
-            b_wo[i] = wo; b_ho[i] = ho;
-            b_base[i] = (unsigned)((b * (int)p.xs_b + (ho * p.stride - p.pad + frr) * (int)p.xs_h + c) * 2);
+            b_wo[i] = wo;
+            b_ho[i] = live ? ho : -(1 << 24);   // a dead slot never passes the hi >= 0 test
+            b_base[i] = (unsigned)((b * (int)p.xs_b + (ho * p.stride + fr - p.pad) * (int)p.xs_h + c) * 2);
         }
     }
     const int step_w = BK % p.Wout, step_h = BK / p.Wout;         // BK pixels = step_h rows + step_w
@@ -128,19 +136,24 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
         const int rows_left = m_end - (m_begin + kt * BK);
         const int a_soff = kt * (BK * 2) * p.K;
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i)
-            a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyr, (int)(a_row[i] < rows_left ? a_voff[i] : 0x80000000u), a_soff, 0);
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int row = (tid + i * 256) / A_CPR;
+            a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyr, (int)(row < rows_left ? a_voff[i] : INVALID), a_soff, 0);
+        }
         if (SIMPLE) {
             const int b_soff = kt * BK * xs_w2;
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i)
-                b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(b_row[i] < rows_left ? b_base[i] : 0x80000000u), b_soff, 0);
+            for (int i = 0; i < B_LOADS; ++i) {
+                const int row = (tid + i * 256) / B_CPR;
+                b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(row < rows_left ? b_base[i] : INVALID), b_soff, 0);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
-                int hi = b_ho[i] * p.stride - p.pad + frr, wi = b_wo[i] * p.stride - p.pad_w + fs;
-                bool ok = (b_row[i] < rows_left) & (hi >= 0) & (hi < p.Hin) & (wi >= 0) & (wi < p.Win);
-                b_reg[i] = wg_load16(xr, ok ? b_base[i] + (unsigned)(wi * xs_w2) : 0x80000000u);
+                int hi = b_ho[i] * p.stride + b_dh[i], wi = b_wo[i] * p.stride + b_dw[i];
+                const int row = (tid + i * 256) / B_CPR;
+                bool ok = (row < rows_left) & (hi >= 0) & (hi < p.Hin) & (wi >= 0) & (wi < p.Win);
+                b_reg[i] = wg_load16(xr, ok ? b_base[i] + (unsigned)(wi * xs_w2) : INVALID);
                 // advance this slot by BK pixels
                 int wo = b_wo[i] + step_w, ho = b_ho[i] + step_h;
                 unsigned base = b_base[i] + (unsigned)(step_h * row_bytes);
@@ -211,20 +224,18 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
         __syncthreads();
     }
 
-    // D rows = n (4 per lane), cols = c (lane & 15)
-    const int RSC = p.R * p.S * p.C;
+    // D rows = n (4 per lane), cols = flattened (r, s, c) index (lane & 15)
     float* out = p.partial + (long long)split * p.K * RSC;
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            int c = c0 + wn * WN + j * 16 + fr;
+            int jc = j0 + wn * WN + j * 16 + fr;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int n = n0 + wm * WM + i * 16 + fq * 4 + e;
-                if (n < p.K && c < p.C)
-                    out[(long long)n * RSC + (frr * p.S + fs) * p.C + c] = acc[i][j][e];
+                if (n < p.K && jc < RSC) out[(long long)n * RSC + jc] = acc[i][j][e];
             }
         }
 }
@@ -275,10 +286,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 template <int BMw, int BNw>
 int launch_wgrad(WgradParams& p, hipStream_t stream) {
     p.tiles_k = (p.K + BMw - 1) / BMw;
-    p.tiles_c = (p.C + BNw - 1) / BNw;
-    dim3 grid(p.tiles_k * p.tiles_c * p.R * p.S * p.splits), block(256);
-    if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false>), grid, block, 0, stream, p);
+    p.tiles_rsc = (p.R * p.S * p.C + BNw - 1) / BNw;
+    dim3 grid(p.tiles_k * p.tiles_rsc * p.splits), block(256);
+    if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true>), grid, block, 0, stream, p);
+    else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false>), grid, block, 0, stream, p);
     return ddl_launch_status();
 }
 
@@ -286,9 +298,23 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
 
 // Split planning shared with the host wrapper: returns the number of reduction splits for a
 // problem so the caller can size the partial workspace (splits * K * R*S*C floats).
+// Tile shape per problem: rows = output channels, columns = flattened (r, s, c).
+static void wgrad_tile(int K, int C, int R, int S, int& bm, int& bn) {
+    const int RSC = R * S * C;
+    bm = K <= 64 ? 64 : 128;
+    if (K <= 64) {
+        if (RSC <= 32) bn = 32;
+        else if (RSC <= 64 || C == 64) bn = 64;   // 64-channel 3x3: one tap per tile measured faster than 3 (192)
+        else bn = 128;                            // incl. the stem: 4 of its 32-wide taps per tile
+    } else {
+        bn = RSC <= 64 ? 64 : 128;
+    }
+}
+
 extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S) {
-    int bm = K <= 64 ? 64 : 128, bn = C <= 32 ? 32 : (C <= 64 ? 64 : 128);
-    long long tiles = (long long)((K + bm - 1) / bm) * ((C + bn - 1) / bn) * R * S;
+    int bm, bn;
+    wgrad_tile(K, C, R, S, bm, bn);
+    long long tiles = (long long)((K + bm - 1) / bm) * ((R * S * C + bn - 1) / bn);
     // Workgroups to aim for, from the DDL_WGRAD_TARGET sweep of benchmarks/kernel_bench.py on
     // MI355X (profiles/r1_notes.md): every workgroup costs one fp32 tile of partial-sum traffic
     // (64 KB for 128x128), so the 1x1 GEMMs want just 2 per CU; 3x3 taps re-read their operands
@@ -337,12 +363,14 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
                 xs_h == (long long)Win * xs_w && xs_b == (long long)Hin * xs_h) ? 1 : 0;
     p.inv_hw = 1.0f / (float)(Hout * Wout);
     p.inv_w = 1.0f / (float)Wout;
-    if (K <= 64) {
-        if (C <= 32) return launch_wgrad<64, 32>(p, stream);
-        if (C <= 64) return launch_wgrad<64, 64>(p, stream);
+    int bm, bn;
+    wgrad_tile(K, C, R, S, bm, bn);
+    if (bm == 64) {
+        if (bn == 32) return launch_wgrad<64, 32>(p, stream);
+        if (bn == 64) return launch_wgrad<64, 64>(p, stream);
         return launch_wgrad<64, 128>(p, stream);
     }
-    if (C <= 64) return launch_wgrad<128, 64>(p, stream);
+    if (bn == 64) return launch_wgrad<128, 64>(p, stream);
     return launch_wgrad<128, 128>(p, stream);
 }
 

@@ -84,6 +84,27 @@ __global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restr
     }
 }
 
+__device__ __forceinline__ void bn_fwd_finish(int c, double s1, double s2, long long M, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, float* __restrict__ rmean,
+                                              float* __restrict__ rvar, float momentum, float eps,
+                                              float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                              float* __restrict__ scale, float* __restrict__ shift) {
+    const double n = (double)M;
+    const double mean = s1 / n;
+    double m2 = s2 - s1 * mean;
+    if (m2 < 0.0) m2 = 0.0;
+    const float var = (float)(m2 / n);
+    const float inv = rsqrtf(var + eps);
+    mean_out[c] = (float)mean; invstd_out[c] = inv;
+    const float g = gamma[c] * inv;
+    scale[c] = g; shift[c] = beta[c] - (float)mean * g;
+    if (rmean) {
+        const float unbiased = M > 1 ? (float)(m2 / (n - 1.0)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+    }
+}
+
 __global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const double* __restrict__ folded, int P, int C, long long M,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ rmean, float* __restrict__ rvar,
@@ -106,19 +127,41 @@ __global__ void __launch_bounds__(256) bn_fwd_finalize_kernel(const double* __re
     }
     s1 = (s1 + t1) + (u1 + w1);
     s2 = (s2 + t2) + (u2 + w2);
-    const double n = (double)M;
-    const double mean = s1 / n;
-    double m2 = s2 - s1 * mean;
-    if (m2 < 0.0) m2 = 0.0;
-    const float var = (float)(m2 / n);
-    const float inv = rsqrtf(var + eps);
-    mean_out[c] = (float)mean; invstd_out[c] = inv;
-    const float g = gamma[c] * inv;
-    scale[c] = g; shift[c] = beta[c] - (float)mean * g;
-    if (rmean) {
-        const float unbiased = M > 1 ? (float)(m2 / (n - 1.0)) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+    bn_fwd_finish(c, s1, s2, M, gamma, beta, rmean, rvar, momentum, eps, mean_out, invstd_out, scale, shift);
+}
+
+// Short partial tables (the 14x14 and 7x7 layers: <= 512 tiles) in ONE launch: 64 channels x 16
+// tile lanes per block, fp64 accumulation, LDS fold, then the same finish as above.
+__global__ void __launch_bounds__(1024) bn_fwd_finalize_direct_kernel(const float* __restrict__ partial, int T, int C, long long M,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                     float momentum, float eps, float* __restrict__ mean_out,
+                                                                     float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                                     float* __restrict__ shift) {
+    __shared__ double r1[16][64], r2[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        int t = ty;
+        for (; t + 48 < T; t += 64) {
+            float a0 = partial[((long long)t * 2) * C + c], b0 = partial[((long long)t * 2 + 1) * C + c];
+            float a1 = partial[((long long)(t + 16) * 2) * C + c], b1 = partial[((long long)(t + 16) * 2 + 1) * C + c];
+            float a2 = partial[((long long)(t + 32) * 2) * C + c], b2 = partial[((long long)(t + 32) * 2 + 1) * C + c];
+            float a3 = partial[((long long)(t + 48) * 2) * C + c], b3 = partial[((long long)(t + 48) * 2 + 1) * C + c];
+            s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; t < T; t += 16) {
+            s1 += (double)partial[((long long)t * 2) * C + c];
+            s2 += (double)partial[((long long)t * 2 + 1) * C + c];
+        }
+    }
+    r1[ty][tx] = s1; r2[ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int l = 1; l < 16; ++l) { s1 += r1[l][tx]; s2 += r2[l][tx]; }
+        bn_fwd_finish(c, s1, s2, M, gamma, beta, rmean, rvar, momentum, eps, mean_out, invstd_out, scale, shift);
     }
 }
 
@@ -558,6 +601,12 @@ extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long 
     CHK(partial && gamma && beta && mean && invstd && scale && shift && workspace && T > 0 && C > 0 && M > 0, DDL_EINVAL);
     CHK((long long)T * rows_per_tile >= M && (long long)(T - 1) * rows_per_tile < M, DDL_EINVAL);
     CHK((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, DDL_EALIGN);
+    if (T <= 512) {
+        hipLaunchKernelGGL(bn_fwd_finalize_direct_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, T, C,
+                           M, (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
+                           (float*)mean, (float*)invstd, (float*)scale, (float*)shift);
+        return ddl_launch_status();
+    }
     const int P = (int)ddl_bn_fold_slices(T);
     hipLaunchKernelGGL(bn_stats_fold_kernel<double>, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
                        (double*)workspace);
@@ -614,7 +663,7 @@ extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long 
                                    const void* invstd, void* dgamma, void* dbeta, void* coef, int accumulate,
                                    void* workspace, hipStream_t stream) {
     CHK(partial && gamma && mean && invstd && dgamma && dbeta && coef && G > 0 && C > 0 && M > 0, DDL_EINVAL);
-    if (workspace && G > 256) {
+    if (workspace && G > 512) {
         const int P = (int)ddl_bn_fold_slices(G);
         hipLaunchKernelGGL(bn_stats_fold_kernel<float>, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const float*)partial, G, C,
                            P, (float*)workspace);

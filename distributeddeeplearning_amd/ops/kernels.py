@@ -245,7 +245,7 @@ def bn_bwd_reduce(dz, y, z, fcoef, partial, M, C, mask, G):
 
 def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef, accumulate=False):
     work = None
-    if G > 256:
+    if G > 512:
         P = int(lib().ddl_bn_fold_slices(_i32(G)))
         work = torch.empty((P, 2, C), dtype=torch.float32, device=partial.device)
     check(lib().ddl_bn_bwd_finalize(ptr(partial), _i32(G), _i32(C), _i64(M), ptr(gamma), ptr(mean),
