@@ -257,16 +257,92 @@ def _conv_dgrad_1x1s2_compact(dy, w):
 
 def _conv_wgrad(dy, x, w, stride, padding):
     """dw for ``w``: written into ``w.grad`` when that is a live arena view (returns None and
-    notifies the listeners), otherwise returned as a new tensor."""
+    notifies the listeners), otherwise returned as a new tensor.
+
+    In direct mode the kernel pair (split-K partials + ordered reduce) runs on a second HIP
+    stream: weight gradients are off the critical path of backward (nothing downstream in the
+    backward pass reads them), so they fill the bubbles the dependent chain dgrad -> BN finalize
+    -> BN apply leaves on the main stream."""
     Kc, _, R, S = w.shape
     Ho, Wo = dy.shape[2], dy.shape[3]
     if _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]:
-        _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                    accumulate=True)
+        side = _side_stream(dy.device) if _SIDE["on"] else None
+        if side is None:
+            _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
+                        accumulate=True)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
+                            accumulate=True)
+            # the caching allocator must not hand these blocks out again before the side stream
+            # is done with them
+            dy.record_stream(side)
+            x.record_stream(side)
+            _side_mark_used()
         _notify(w)
         return None
     return _wgrad_into(dy, x, _geom(x), torch.empty_like(w), Kc, R, S, stride, padding, padding,
                        Ho, Wo)
+
+
+# ---- second stream for weight gradients --------------------------------------------------------
+_SIDE = {"on": True, "stream": None, "pending": False}
+
+
+def set_wgrad_side_stream(on: bool):
+    _SIDE["on"] = bool(on)
+
+
+def _side_stream(device):
+    st = _SIDE["stream"]
+    if st is None or st.device != device:
+        st = _SIDE["stream"] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _join_side_stream():
+    """Order the current stream after everything queued on the weight-gradient stream."""
+    st = _SIDE["stream"]
+    if st is not None and _SIDE["pending"]:
+        cur = torch.cuda.current_stream(st.device)
+        cur.wait_stream(st)
+        main = _SIDE.get("main")
+        if main is not None and main != cur:  # the stream backward ran on
+            main.wait_stream(st)
+    _SIDE["pending"] = False
+
+
+def _side_mark_used():
+    # the join is queued once per backward pass: it runs when autograd finishes the pass, so
+    # whoever reads param.grad afterwards (optimizer, clipping, tests) is ordered correctly
+    if not _SIDE["pending"]:
+        _SIDE["pending"] = True
+        _SIDE["main"] = torch.cuda.current_stream()
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+        except RuntimeError:  # not inside a backward pass (raw calls in tests / benchmarks)
+            pass
+
+
+class grad_exchange_context:
+    """Context for launching a gradient collective from a readiness notification: the launch
+    happens on the weight-gradient stream after it has been ordered behind the main stream, so
+    the collective sees the gradients written on either of them."""
+
+    def __enter__(self):
+        st = _SIDE["stream"]
+        self.cm = None
+        if st is not None and _SIDE["pending"]:
+            st.wait_stream(torch.cuda.current_stream(st.device))
+            self.cm = torch.cuda.stream(st)
+            self.cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.cm is not None:
+            self.cm.__exit__(*exc)
+        return False
 
 
 _DIRECT = {"on": False}

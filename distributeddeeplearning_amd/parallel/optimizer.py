@@ -36,6 +36,25 @@ from .compression import Compression
 __all__ = ["DistributedOptimizer"]
 
 
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _grad_exchange_context():
+    """Fused HIP blocks may have written some gradients of the bucket on their weight-gradient
+    stream: launch the collective where it is ordered after both streams."""
+    try:
+        from ..ops import hip_ops as _hip_ops
+
+        return _hip_ops.grad_exchange_context()
+    except Exception:  # pragma: no cover - ops layer unavailable
+        return _NullContext()
+
+
 class _BucketState:
     __slots__ = ("dtype", "bucket", "tensor", "pending", "expected", "work", "launched",
                  "needs_scale", "wire", "ctx")
@@ -136,16 +155,17 @@ class _DistributedMixin:
         name = "grad.%s.bucket%d" % (str(st.dtype).replace("torch.", ""), st.bucket.index)
         _tl.begin(name, "ALLREDUCE")
         buf = st.tensor
-        wire, ctx = self._ddl_compression.compress(buf)
-        if _b.backend_name() == "gloo" and wire.is_cuda:
-            wire = wire.cpu()
-        st.wire, st.ctx = wire, ctx
-        if _b.supports_avg():
-            st.work = _b.comm().all_reduce(wire, "average", name)
-            st.needs_scale = False
-        else:
-            st.work = _b.comm().all_reduce(wire, "sum", name)
-            st.needs_scale = True
+        with _grad_exchange_context():
+            wire, ctx = self._ddl_compression.compress(buf)
+            if _b.backend_name() == "gloo" and wire.is_cuda:
+                wire = wire.cpu()
+            st.wire, st.ctx = wire, ctx
+            if _b.supports_avg():
+                st.work = _b.comm().all_reduce(wire, "average", name)
+                st.needs_scale = False
+            else:
+                st.work = _b.comm().all_reduce(wire, "sum", name)
+                st.needs_scale = True
 
     def _ddl_finish(self, st):
         if st.work is None:
@@ -173,6 +193,12 @@ class _DistributedMixin:
         for st in self._ddl_buckets:
             if not st.launched:
                 self._ddl_launch(st)
+        try:
+            from ..ops import hip_ops as _hip_ops
+
+            _hip_ops._join_side_stream()
+        except Exception:  # pragma: no cover - ops layer unavailable
+            pass
         for st in self._ddl_buckets:
             self._ddl_finish(st)
         self._ddl_verify_order_once()
