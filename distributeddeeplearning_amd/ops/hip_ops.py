@@ -295,9 +295,26 @@ def set_wgrad_side_stream(on: bool):
 
 
 def _side_stream(device):
+    """The weight-gradient stream: created through HIP with the LOWEST priority the device offers.
+    A priority of its own also gives it a hardware queue of its own (streams of equal priority
+    share the few HIP hardware queues round-robin, and two streams on one queue serialise — a
+    pool stream from torch landed on the default stream's queue, profiles/r1_notes.md), and the
+    dependent main-stream chain wins when both have workgroups to place."""
     st = _SIDE["stream"]
     if st is None or st.device != device:
-        st = _SIDE["stream"] = torch.cuda.Stream(device=device)
+        import os
+
+        prio = os.environ.get("DDL_WGRAD_STREAM_PRIORITY", "low")
+        if prio == "torch":
+            st = torch.cuda.Stream(device=device)
+        else:
+            with torch.cuda.device(device):
+                least, greatest = K.stream_priority_range()
+                want = {"low": least, "high": greatest}.get(prio)
+                if want is None:
+                    want = int(prio)
+                st = torch.cuda.ExternalStream(K.create_stream(want), device=device)
+        _SIDE["stream"] = st
     return st
 
 

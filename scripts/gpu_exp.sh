@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-for t in 256 384 640 896 3072 4096; do
-  echo "== DDL_WGRAD_TARGET=$t"
-  DDL_WGRAD_TARGET=$t timeout -k 10 300 python -u benchmarks/kernel_bench.py --iters 20 2>&1 | grep -v amdgpu.ids > gpurun_out/kb_wt$t.log || exit 1
-  awk '{printf "%s:%s ", $1, $8}' gpurun_out/kb_wt$t.log; echo; tail -1 gpurun_out/kb_wt$t.log
+for p in low high; do
+  echo "== DDL_WGRAD_STREAM_PRIORITY=$p"
+  DDL_WGRAD_STREAM_PRIORITY=$p timeout -k 10 200 python -u bench.py --steps 20 --warmup 5 2>&1 | tail -1 | cut -c95-260 || exit 1
+  DDL_WGRAD_STREAM_PRIORITY=$p HVD_FORCE_COLLECTIVES=1 timeout -k 10 200 python -u bench.py --steps 20 --warmup 5 2>&1 | tail -1 | cut -c95-260 || exit 1
 done
