@@ -598,7 +598,8 @@ extern "C" long long ddl_bn_fold_slices(int T) {
 extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long M, int rows_per_tile, const void* gamma,
                                    const void* beta, void* rmean, void* rvar, float momentum, float eps, void* mean,
                                    void* invstd, void* scale, void* shift, void* workspace, hipStream_t stream) {
-    CHK(partial && gamma && beta && mean && invstd && scale && shift && workspace && T > 0 && C > 0 && M > 0, DDL_EINVAL);
+    CHK(partial && gamma && beta && mean && invstd && scale && shift && T > 0 && C > 0 && M > 0, DDL_EINVAL);
+    CHK(workspace || T <= 512, DDL_EINVAL);
     CHK((long long)T * rows_per_tile >= M && (long long)(T - 1) * rows_per_tile < M, DDL_EINVAL);
     CHK((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, DDL_EALIGN);
     if (T <= 512) {

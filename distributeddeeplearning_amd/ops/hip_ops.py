@@ -431,6 +431,85 @@ def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True, part
     return dy, dg, db, g
 
 
+# ---- lean conv-BN unit used by the fused blocks ---------------------------------------------------
+# Same kernels as _conv_fwd/_bn_fwd/_bn_bwd, but per-layer scratch (statistics partials, fold
+# workspace, backward coefficients) lives in ONE allocation addressed by raw pointers, and the
+# saved [4, C] coefficient block is addressed the same way: each avoided tensor object (an
+# allocation or a view) is 3-5 us of host time, ~30 of them per layer and step, and the host has
+# to keep ahead of ~50 us kernels in the late layers (profiles/r1_notes.md).
+def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentum, eps, relu):
+    """Training-mode conv -> BatchNorm(+residual)(+ReLU).  Returns (y, z, coeffs[4, C])."""
+    B, C, H, W = x.shape
+    Kc, Cw, R, S = w.shape
+    if Cw != C:
+        raise K.KernelError("conv: input has %d channels, weight expects %d" % (C, Cw))
+    Ho = (H + 2 * padding - R) // stride + 1
+    Wo = (W + 2 * padding - S) // stride + 1
+    M = B * Ho * Wo
+    T = K.conv_tiles_m(M)
+    P = K._fold_slices(T) if T > 512 else 0
+    dev = x.device
+    y = torch.empty((B, Kc, Ho, Wo), dtype=_BF16, device=dev, memory_format=_CL)
+    coeffs = torch.empty((4, Kc), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+    tmp = torch.empty(2 * T * Kc + 4 * P * Kc, dtype=torch.float32, device=dev)
+    st = tmp.data_ptr()
+    wk = st + 8 * T * Kc if P else None      # fp64 fold workspace (8-byte aligned: T*Kc*8 bytes in)
+    K.conv_igemm(x, _geom(x), w, y, Kc, R, S, stride, padding, padding, 1, Ho, Wo, stats=st)
+    cb = coeffs.data_ptr()
+    K.bn_fwd_finalize(st, T, Kc, M, 128, gamma, beta, rmean, rvar, momentum, eps,
+                      cb, cb + 4 * Kc, cb + 8 * Kc, cb + 12 * Kc, work=wk)
+    z = torch.empty_like(y)
+    K.bn_apply_fwd(y, cb + 8 * Kc, cb + 12 * Kc, residual, z, M, Kc, relu)
+    return y, z, coeffs
+
+
+def _unit_bwd(dz, y, z, gamma, beta, coeffs, mask, want_g, partial=None):
+    """BatchNorm(+ReLU) backward of one unit.  ``mask``: 0 none (``dz`` is final), 1 from ``z``,
+    2 recomputed from ``y``.  ``partial`` = reduce partials already produced by a conv epilogue.
+    Returns (dy, dgamma, dbeta, g) like _bn_bwd."""
+    B, C, H, W = y.shape
+    M = B * H * W
+    dev = y.device
+    cb = coeffs.data_ptr()
+    fco = cb + 8 * C if mask == 2 else None
+    if partial is None:
+        G = K.bn_bwd_blocks(M)
+        own = 2 * G * C
+    else:
+        G = partial.shape[0]
+        own = 0
+    P = K._fold_slices(G) if G > 512 else 0
+    tmp = torch.empty(3 * C + own + 2 * P * C, dtype=torch.float32, device=dev)
+    coef = tmp.data_ptr()
+    if partial is None:
+        part = coef + 12 * C
+        K.bn_bwd_reduce(dz, y, z if mask == 1 else None, fco, part, M, C, mask, G)
+    else:
+        part = partial.data_ptr()
+    wk = coef + 12 * C + 4 * own if P else None
+    direct = _DIRECT["on"] and _direct_grad_ok(gamma) and _direct_grad_ok(beta) and \
+        gamma.grad.dtype == torch.float32 and beta.grad.dtype == torch.float32
+    if direct:
+        K.bn_bwd_finalize(part, G, C, M, gamma, cb, cb + 4 * C, gamma.grad, beta.grad, coef,
+                          accumulate=True, work=wk)
+        dg = db = None
+    else:
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        K.bn_bwd_finalize(part, G, C, M, gamma, cb, cb + 4 * C, dgb[0], dgb[1], coef, work=wk)
+        dg, db = dgb[0], dgb[1]
+    dy = torch.empty_like(y)
+    g = torch.empty_like(y) if (want_g and mask != 0) else None
+    K.bn_bwd_apply(dz, y, z if mask == 1 else None, fco, coef, dy, g, M, C, mask)
+    if want_g and mask == 0:
+        g = dz
+    if direct:
+        _notify(gamma)
+        _notify(beta)
+    # tmp is only referenced by raw address from here on: the launches above are already queued
+    # on this stream and the allocator hands the block out again in stream order
+    return dy, dg, db, g
+
+
 class ConvFn(Function):
     """y = conv2d(x, w) (no bias); optionally also the per-tile BatchNorm partial sums."""
 
@@ -600,15 +679,24 @@ class ResidualBlockFn(Function):
         yd = cd = None
         if has_ds:
             wd, gd, bd, rmd, rvd = groups[units]
-            yd, st = _conv_fwd(x, wd, ds_stride, 0, training)
-            shortcut, cd = _bn_fwd(yd, gd, bd, None, st, rmd, rvd, training, momentum, eps, False)
+            if training:
+                yd, shortcut, cd = _unit_fwd(x, wd, ds_stride, 0, gd, bd, None, rmd, rvd, momentum,
+                                             eps, False)
+            else:
+                yd, st = _conv_fwd(x, wd, ds_stride, 0, training)
+                shortcut, cd = _bn_fwd(yd, gd, bd, None, st, rmd, rvd, training, momentum, eps,
+                                       False)
         cur = x
         for i in range(units):
             w, g, b, rm, rv = groups[i]
-            y, st = _conv_fwd(cur, w, strides[i], pads[i], training)
             last = i == units - 1
-            z, c = _bn_fwd(y, g, b, shortcut if last else None, st, rm, rv, training, momentum,
-                           eps, True)
+            if training:
+                y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, shortcut if last else None,
+                                    rm, rv, momentum, eps, True)
+            else:
+                y, st = _conv_fwd(cur, w, strides[i], pads[i], training)
+                z, c = _bn_fwd(y, g, b, shortcut if last else None, st, rm, rv, training,
+                               momentum, eps, True)
             saved_y.append(y)
             saved_z.append(z)
             saved_c.append(c)
@@ -654,9 +742,11 @@ class ResidualBlockFn(Function):
         for i in range(units - 1, -1, -1):
             w, gam, bet = groups[i][0], groups[i][1], groups[i][2]
             last = i == units - 1
-            dy, dg, db, g = _bn_bwd(dz, ys[i], zs[i], gam, cs[i], True, last, beta=bet,
-                                    has_res=last, partial=fused,
-                                    premasked=last and grad_premasked)
+            if fused is not None or (last and grad_premasked):
+                mask = 0            # dz already carries the ReLU mask
+            else:
+                mask = 1 if last else 2
+            dy, dg, db, g = _unit_bwd(dz, ys[i], zs[i], gam, bet, cs[i], mask, last, partial=fused)
             if last:
                 g_short = g
             inp = zs[i - 1] if i > 0 else x
@@ -665,7 +755,7 @@ class ResidualBlockFn(Function):
             if i > 0:
                 if _FUSE_BN_REDUCE["on"]:
                     dz, fused = _conv_dgrad_bn(dy, w, inp.shape, strides[i], pads[i], ys[i - 1],
-                                               cs[i - 1][2:4])
+                                               cs[i - 1].data_ptr() + 8 * inp.shape[1])
                 else:
                     dz, fused = _conv_dgrad(dy, w, inp.shape, strides[i], pads[i]), None
             else:
@@ -673,7 +763,7 @@ class ResidualBlockFn(Function):
                 if has_ds:
                     wd, gd, bd = groups[units][0], groups[units][1], groups[units][2]
                     yd, cd = saved[1 + 3 * units], saved[2 + 3 * units]
-                    dyd, dgd, dbd, _ = _bn_bwd(g_short, yd, None, gd, cd, False, False, beta=bd)
+                    dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False)
                     dwd = _conv_wgrad(dyd, x, wd, ds_stride, 0)
                     put(units, dwd, dgd, dbd)
                     if ctx.needs_input_grad[0]:

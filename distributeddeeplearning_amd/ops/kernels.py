@@ -76,7 +76,11 @@ def _raw_stream():
 
 
 def _p(t):
-    return None if t is None else t.data_ptr()
+    """Device address of a tensor; raw addresses (ints: slices of a per-layer scratch block, which
+    cost a tensor object each when expressed as views) pass through."""
+    if t is None:
+        return None
+    return t if t.__class__ is int else t.data_ptr()
 
 
 _hip_rt = None
@@ -223,14 +227,15 @@ def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil,
     for t in (ep_y, ep_mask):
         if t is not None and t.numel() != y.numel():
             raise KernelError("conv_igemm: epilogue tensor does not match the output shape")
-    if ep_fcoef is not None and (ep_fcoef.numel() != 2 * n_out or not ep_fcoef.is_contiguous()):
+    if ep_fcoef is not None and ep_fcoef.__class__ is not int and \
+            (ep_fcoef.numel() != 2 * n_out or not ep_fcoef.is_contiguous()):
         raise KernelError("conv_igemm: ep_fcoef must be a contiguous [2, N] tensor")
-    if ep_y is not None:
+    if ep_y is not None and stats.__class__ is not int:
         need = conv_tiles_m_bwd(y.numel() // n_out, Hout, Wout, idil, ostride) * 2 * n_out
         if stats is None or stats.numel() < need:
             raise KernelError("conv_igemm: partial buffer too small for the fused reduce")
     f = _fn("ddl_conv_igemm_ex", "ppppp qq iiii qqq iiiiiiiiii pppp")
-    check(f(x_ptr_tensor.data_ptr(), w.data_ptr(), y.data_ptr(), _p(addend), _p(stats), xn,
+    check(f(x_ptr_tensor.data_ptr(), _p(w), y.data_ptr(), _p(addend), _p(stats), xn,
             w.numel(), B, Hin, Win, C, sb, sh, sw, Hout, Wout, n_out, R, S, ostride, pad, pad_w, idil,
             1 if addend_sub2 else 0, _p(ep_y), _p(ep_fcoef), _p(ep_mask), _raw_stream()),
           "conv_igemm")
@@ -279,13 +284,15 @@ def _fold_slices(T):
 
 
 def bn_fwd_finalize(partial, T, C, M, rows_per_tile, gamma, beta, rmean, rvar, momentum, eps,
-                    mean, invstd, scale, shift):
-    P = _fold_slices(T)
-    work = torch.empty((P, 2, C), dtype=torch.float64, device=partial.device)
+                    mean, invstd, scale, shift, work=None):
+    """``work``: [fold_slices(T), 2, C] float64 scratch, needed (and allocated here unless given)
+    only for tables of more than 512 tiles."""
+    if work is None and T > 512:
+        work = torch.empty((_fold_slices(T), 2, C), dtype=torch.float64, device=partial.device)
     f = _fn("ddl_bn_fwd_finalize", "p iiqi pppp ff ppppp p")
-    check(f(partial.data_ptr(), T, C, M, rows_per_tile, gamma.data_ptr(), beta.data_ptr(), _p(rmean),
-            _p(rvar), momentum, eps, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
-            shift.data_ptr(), work.data_ptr(), _raw_stream()), "bn_fwd_finalize")
+    check(f(_p(partial), T, C, M, rows_per_tile, gamma.data_ptr(), beta.data_ptr(), _p(rmean),
+            _p(rvar), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), _p(work),
+            _raw_stream()), "bn_fwd_finalize")
 
 
 def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):
@@ -296,7 +303,7 @@ def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):
 
 def bn_apply_fwd(y, scale, shift, res, z, M, C, relu):
     f = _fn("ddl_bn_apply_fwd", "ppppp qii p")
-    check(f(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), _p(res), z.data_ptr(), M, C,
+    check(f(y.data_ptr(), _p(scale), _p(shift), _p(res), z.data_ptr(), M, C,
             1 if relu else 0, _raw_stream()), "bn_apply_fwd")
 
 
@@ -307,24 +314,23 @@ def bn_bwd_blocks(M):
 
 def bn_bwd_reduce(dz, y, z, fcoef, partial, M, C, mask, G):
     f = _fn("ddl_bn_bwd_reduce", "ppppp qiii p")
-    check(f(dz.data_ptr(), y.data_ptr(), _p(z), _p(fcoef), partial.data_ptr(), M, C, mask, G,
+    check(f(dz.data_ptr(), y.data_ptr(), _p(z), _p(fcoef), _p(partial), M, C, mask, G,
             _raw_stream()), "bn_bwd_reduce")
 
 
-def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef, accumulate=False):
-    work = None
-    if G > 512:
-        P = _fold_slices(G)
-        work = torch.empty((P, 2, C), dtype=torch.float32, device=partial.device)
+def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef, accumulate=False,
+                    work=None):
+    """``work``: [fold_slices(G), 2, C] float32 scratch for tables of more than 512 rows."""
+    if work is None and G > 512:
+        work = torch.empty((_fold_slices(G), 2, C), dtype=torch.float32, device=gamma.device)
     f = _fn("ddl_bn_bwd_finalize", "p iiq pppppp i pp")
-    check(f(partial.data_ptr(), G, C, M, gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-            dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), 1 if accumulate else 0, _p(work),
-            _raw_stream()), "bn_bwd_finalize")
+    check(f(_p(partial), G, C, M, gamma.data_ptr(), _p(mean), _p(invstd), _p(dgamma), _p(dbeta),
+            _p(coef), 1 if accumulate else 0, _p(work), _raw_stream()), "bn_bwd_finalize")
 
 
 def bn_bwd_apply(dz, y, z, fcoef, coef, dy, gout, M, C, mask):
     f = _fn("ddl_bn_bwd_apply", "ppppppp qii p")
-    check(f(dz.data_ptr(), y.data_ptr(), _p(z), _p(fcoef), coef.data_ptr(), dy.data_ptr(), _p(gout), M,
+    check(f(dz.data_ptr(), y.data_ptr(), _p(z), _p(fcoef), _p(coef), dy.data_ptr(), _p(gout), M,
             C, mask, _raw_stream()), "bn_bwd_apply")
 
 
