@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <stdint.h>
 
 #define DDL_OK 0
@@ -53,10 +54,14 @@ static inline int ddl_launch_status_at(const char* file, int line) {
 #define ddl_launch_status() ddl_launch_status_at(__FILE__, __LINE__)
 static inline bool ddl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Grid sizing for memory-bound grid-stride kernels: cap at 256 CUs x 8 blocks.
+// Grid sizing for memory-bound grid-stride kernels.  Measured with benchmarks/native/stream_bench
+// (BN-apply shaped kernel, 411 MB in + 411 MB out): 2048 blocks 5.08 TB/s, 16384 5.43, 65536 5.90 —
+// many short-lived blocks beat few long grid-stride loops on 256 CUs (tensors that fit the
+// 256 MB infinity cache run at ~7.8 TB/s for any grid), so the cap is 65536 blocks.
 static inline int ddl_stream_grid(long long work_items, int block) {
+    static const int cap = getenv("DDL_STREAM_GRID_CAP") ? atoi(getenv("DDL_STREAM_GRID_CAP")) : 65536;  // tuning knob
     long long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;
+    if (g > cap) g = cap;
     return (int)g;
 }

@@ -267,23 +267,23 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
                     ao = ((long long)(b * (p.Hout >> 1) + (hi >> 1)) * (p.Wout >> 1) + (wi >> 1)) * p.N + n;
                 }
                 if (has) {
-                    bf16x8 a = *reinterpret_cast<const bf16x8*>(p.addend + ao);
+                    bf16x8 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.addend + ao));
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(a[e]));
                 }
             }
             if (EPI == 3 || EPI == 4) {
-                bf16x8 zm = *reinterpret_cast<const bf16x8*>(p.ep_mask + o);
+                bf16x8 zm = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_mask + o));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = bf2f(zm[e]) > 0.f ? v[e] : f2bf(0.f);
             }
             if (EPI == 4) {
-                bf16x8 yv = *reinterpret_cast<const bf16x8*>(p.ep_y + o);
+                bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_y + o));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float g = bf2f(v[e]); s1[e] += g; s2[e] += g * bf2f(yv[e]); }
             }
             if (EPI == 2) {
-                bf16x8 yv = *reinterpret_cast<const bf16x8*>(p.ep_y + o);
+                bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_y + o));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float yf = bf2f(yv[e]);

@@ -6,8 +6,27 @@
 //   K13 softmax cross-entropy fwd+bwd in one pass, bias add, K3 helper: weight flip-transpose
 // All: wave64, 256-thread blocks unless noted, 16-byte (8 x bf16) lanes, fp32 math.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
+
+// Streaming loads / stores with the non-temporal hint.  In isolation (benchmarks/native/
+// stream_bench) the hint gains 10-15 % GB/s on tensors larger than the 256 MB infinity cache and
+// loses on smaller ones; inside the training step, where ~30 GB stream through per iteration, it
+// wins for every size (bench.py: 21.61 ms never, 21.42 ms >= 256 MB, 21.18 >= 128 MB, 21.01 always),
+// so the threshold defaults to 0.
+template <bool NT> __device__ __forceinline__ bf16x8 ld8(const bf16_t* p) {
+    const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
+    return NT ? __builtin_nontemporal_load(q) : *q;
+}
+template <bool NT> __device__ __forceinline__ void st8(bf16_t* p, bf16x8 v) {
+    bf16x8* q = reinterpret_cast<bf16x8*>(p);
+    if (NT) __builtin_nontemporal_store(v, q); else *q = v;
+}
+static long long nt_threshold_bytes() {
+    static const long long v = getenv("DDL_NT_BYTES") ? atoll(getenv("DDL_NT_BYTES")) : 0LL;  // tuning knob
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // K6a: standalone statistics partials [T][2][C] over tiles of `rows_per_tile` rows (used when the
@@ -179,18 +198,18 @@ __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 // K7: z = act(y*scale[c] + shift[c] [+ residual])
 // ---------------------------------------------------------------------------------------------
-template <bool RELU, bool RES>
+template <bool RELU, bool RES, bool NT>
 __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const bf16_t* __restrict__ res,
                                                           bf16_t* __restrict__ z, long long nchunks, int cchunks) {
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
         int c = (int)(i % cchunks) * 8;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(y + (i << 3));
+        bf16x8 v = ld8<NT>(y + (i << 3));
         float sc[8], sh[8];
         load8f(scale + c, sc); load8f(shift + c, sh);
         bf16x8 r;
-        if (RES) r = *reinterpret_cast<const bf16x8*>(res + (i << 3));
+        if (RES) r = ld8<NT>(res + (i << 3));
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -199,7 +218,7 @@ __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restr
             if (RELU) f = fmaxf(f, 0.f);
             o[e] = f2bf(f);
         }
-        *reinterpret_cast<bf16x8*>(z + (i << 3)) = o;
+        st8<NT>(z + (i << 3), o);
     }
 }
 
@@ -290,7 +309,7 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __re
 }
 
 // K8c: dy = ca*g + cb*y + cc ; optionally also store g (gradient of the residual branch)
-template <int MASK, bool WRITE_G>
+template <int MASK, bool WRITE_G, bool NT>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
                                                           const bf16_t* __restrict__ z, const float* __restrict__ fcoef,
                                                           const float* __restrict__ coef,
@@ -300,10 +319,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
         int c = (int)(i % cchunks) * 8;
-        bf16x8 d = *reinterpret_cast<const bf16x8*>(dz + (i << 3));
-        bf16x8 yv = *reinterpret_cast<const bf16x8*>(y + (i << 3));
+        bf16x8 d = ld8<NT>(dz + (i << 3));
+        bf16x8 yv = ld8<NT>(y + (i << 3));
         bf16x8 zv;
-        if (MASK == 1) zv = *reinterpret_cast<const bf16x8*>(z + (i << 3));
+        if (MASK == 1) zv = ld8<NT>(z + (i << 3));
         float ca[8], cb[8], c0[8], sc[8], sh[8];
         load8f(coef + c, ca); load8f(coef + C + c, cb); load8f(coef + 2 * C + c, c0);
         if (MASK == 2) { load8f(fcoef + c, sc); load8f(fcoef + C + c, sh); }
@@ -316,8 +335,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             o[e] = f2bf(ca[e] * g + cb[e] * yf + c0[e]);
             if (WRITE_G) go[e] = f2bf(g);
         }
-        *reinterpret_cast<bf16x8*>(dy + (i << 3)) = o;
-        if (WRITE_G) *reinterpret_cast<bf16x8*>(gout + (i << 3)) = go;
+        st8<NT>(dy + (i << 3), o);
+        if (WRITE_G) st8<NT>(gout + (i << 3), go);
     }
 }
 
@@ -631,9 +650,12 @@ extern "C" int ddl_bn_apply_fwd(const void* y, const void* scale, const void* sh
     CHK(ddl_aligned16(y) && ddl_aligned16(z) && ddl_aligned16(scale) && ddl_aligned16(shift) && (!res || ddl_aligned16(res)), DDL_EALIGN);
     long long nchunks = M * (C >> 3);
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
-#define L(R, S) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S>), grid, block, 0, stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (bf16_t*)z, nchunks, C >> 3)
+    const bool nt = M * C * 2 >= nt_threshold_bytes();
+#define L2(R, S, N) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S, N>), grid, block, 0, stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (bf16_t*)z, nchunks, C >> 3)
+#define L(R, S) do { if (nt) L2(R, S, true); else L2(R, S, false); } while (0)
     if (relu) { if (res) L(true, true); else L(true, false); }
     else { if (res) L(false, true); else L(false, false); }
+#undef L2
 #undef L
     return ddl_launch_status();
 }
@@ -685,11 +707,14 @@ extern "C" int ddl_bn_bwd_apply(const void* dz, const void* y, const void* z, co
         (!gout || ddl_aligned16(gout)) && (!fcoef || ddl_aligned16(fcoef)), DDL_EALIGN);
     long long nchunks = M * (C >> 3);
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
-#define L(MK, G) hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, G>), grid, block, 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
+    const bool nt = M * C * 2 >= nt_threshold_bytes();
+#define L2(MK, G, N) hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, G, N>), grid, block, 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
+#define L(MK, G) do { if (nt) L2(MK, G, true); else L2(MK, G, false); } while (0)
     if (mask == 1) { if (gout) L(1, true); else L(1, false); }
     else if (mask == 2) { if (gout) L(2, true); else L(2, false); }
     else { if (gout) L(0, true); else L(0, false); }
 #undef L
+#undef L2
     return ddl_launch_status();
 }
 
