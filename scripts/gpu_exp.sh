@@ -1,5 +1,7 @@
 #!/bin/bash
-for c in 268435456 1099511627776 134217728 67108864 0; do
-  echo "== DDL_NT_BYTES=$c"
-  DDL_NT_BYTES=$c timeout -k 10 200 python -u bench.py --steps 20 --warmup 5 2>&1 | tail -1 | cut -c95-230 || exit 1
-done
+mkdir -p gpurun_out
+timeout -k 10 300 python -u bench.py --steps 20 --warmup 5 --optimizer lars 2>&1 | tail -1 | tee gpurun_out/bench_lars.log || exit 1
+timeout -k 10 300 python -u bench.py --steps 15 --warmup 5 --model resnet152 2>&1 | tail -1 | tee gpurun_out/bench_r152.log || exit 1
+timeout -k 10 300 python -u bench.py --steps 15 --warmup 5 --model resnet101 2>&1 | tail -1 | tee gpurun_out/bench_r101.log || exit 1
+timeout -k 10 300 python -u bench.py --steps 20 --warmup 5 --model resnet18 2>&1 | tail -1 | tee gpurun_out/bench_r18.log || exit 1
+timeout -k 10 300 python -u bench.py --steps 20 --warmup 5 --batch 512 2>&1 | tail -1 | tee gpurun_out/bench_b512.log || exit 1
