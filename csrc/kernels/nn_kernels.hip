@@ -661,7 +661,9 @@ extern "C" int ddl_bn_apply_fwd(const void* y, const void* scale, const void* sh
 }
 
 extern "C" int ddl_bn_bwd_blocks(long long M) {
-    long long g = (M + 255) / 256;
+    // 32 rows per block at least, up to 1024 blocks: the 7x7 layers (M = 12544) ran 49 blocks of
+    // 256 rows and took 142 us for 50 MB (rocprof, profiles/r1_pmc_training_step.md)
+    long long g = (M + 31) / 32;
     if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     return (int)g;
