@@ -245,59 +245,87 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; fsc[e] = 0.f; fsh[e] = 0.f; }
     if (EPI == 2 && n < p.N) { load8f(p.ep_fcoef + n, fsc); load8f(p.ep_fcoef + p.N + n, fsh); }
+    // Rows are handled in batches: all global reads of a batch (shortcut gradient, ReLU mask, BN
+    // input) are issued back to back with clamped addresses — no branch and no wait between them —
+    // and only then consumed.  (One branchy row at a time made hipcc emit `s_waitcnt vmcnt(0)`
+    // after every load: 2-3 exposed memory round trips per row, 3.3 TB/s on the layer-1 EPI-4
+    // kernel against 4.5 TB/s for a plain streaming kernel — profiles/r1_notes.md.)
+    constexpr int BATCH = OITER < 4 ? OITER : 4;
+    const bool col_ok = n < p.N;
 #pragma unroll
-    for (int it = 0; it < OITER; ++it) {
-        int row = orow0 + it * ORPP, m = m0 + row;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OSTR + oc * 16);
-        if (m < m_lim && n < p.N) {
+    for (int it0 = 0; it0 < OITER; it0 += BATCH) {
+        long long off[BATCH], aoff[BATCH];
+        bool ok[BATCH], has[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            int row = orow0 + (it0 + b) * ORPP, m = m0 + row;
+            ok[b] = (m < m_lim) & col_ok;
             if (p.parity) {  // class-local row -> pixel row of the output image
-                int b = m / hw, rem = m - b * hw;
+                int bb = m / hw, rem = m - bb * hw;
                 int hh = rem / Wq, wh = rem - hh * Wq;
-                m = (b * p.Hout + 2 * hh + ph) * p.Wout + 2 * wh + pw;
+                m = (bb * p.Hout + 2 * hh + ph) * p.Wout + 2 * wh + pw;
             }
             long long o = (long long)m * p.N + n;
+            off[b] = ok[b] ? o : 0;
+            has[b] = false; aoff[b] = 0;
             if (ADDEND) {
                 long long ao = o;
-                bool has = true;
+                bool h = ok[b];
                 if (p.addend_sub2) {
                     int img = p.Hout * p.Wout;
-                    int b = m / img, rem = m - b * img;
+                    int bb = m / img, rem = m - bb * img;
                     int hi = rem / p.Wout, wi = rem - hi * p.Wout;
-                    has = ((hi | wi) & 1) == 0;
-                    ao = ((long long)(b * (p.Hout >> 1) + (hi >> 1)) * (p.Wout >> 1) + (wi >> 1)) * p.N + n;
+                    h = h & (((hi | wi) & 1) == 0);
+                    ao = ((long long)(bb * (p.Hout >> 1) + (hi >> 1)) * (p.Wout >> 1) + (wi >> 1)) * p.N + n;
                 }
-                if (has) {
-                    bf16x8 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.addend + ao));
+                has[b] = h; aoff[b] = h ? ao : 0;
+            }
+        }
+        bf16x8 av[BATCH], zm[BATCH], yv[BATCH];
+        if (ADDEND) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(a[e]));
-                }
+            for (int b = 0; b < BATCH; ++b) av[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.addend + aoff[b]));
+        }
+        if (EPI == 3 || EPI == 4) {
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) zm[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_mask + off[b]));
+        }
+        if (EPI == 2 || EPI == 4) {
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) yv[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_y + off[b]));
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            int row = orow0 + (it0 + b) * ORPP;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(Os + row * OSTR + oc * 16);
+            if (ADDEND) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = has[b] ? f2bf(bf2f(v[e]) + bf2f(av[b][e])) : v[e];
             }
             if (EPI == 3 || EPI == 4) {
-                bf16x8 zm = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_mask + o));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = bf2f(zm[e]) > 0.f ? v[e] : f2bf(0.f);
+                for (int e = 0; e < 8; ++e) v[e] = bf2f(zm[b][e]) > 0.f ? v[e] : f2bf(0.f);
             }
+            const float live = ok[b] ? 1.f : 0.f;   // rows past the edge add nothing to the sums
             if (EPI == 4) {
-                bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_y + o));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float g = bf2f(v[e]); s1[e] += g; s2[e] += g * bf2f(yv[e]); }
+                for (int e = 0; e < 8; ++e) { float g = bf2f(v[e]) * live; s1[e] += g; s2[e] += g * bf2f(yv[b][e]); }
             }
             if (EPI == 2) {
-                bf16x8 yv = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_y + o));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float yf = bf2f(yv[e]);
+                    float yf = bf2f(yv[b][e]);
                     bool on = bn_affine(yf, fsc[e], fsh[e]) > 0.f;
                     v[e] = on ? v[e] : f2bf(0.f);
-                    float g = bf2f(v[e]);
+                    float g = bf2f(v[e]) * live;
                     s1[e] += g; s2[e] += g * yf;
                 }
             }
-            *reinterpret_cast<bf16x8*>(p.y + o) = v;
             if (EPI == 1) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float f = bf2f(v[e]); s1[e] += f; s2[e] += f * f; }
+                for (int e = 0; e < 8; ++e) { float f = bf2f(v[e]) * live; s1[e] += f; s2[e] += f * f; }
             }
+            if (ok[b]) *reinterpret_cast<bf16x8*>(p.y + off[b]) = v;
         }
     }
     if (STATS) {
