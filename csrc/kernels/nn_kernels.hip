@@ -344,47 +344,100 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
 // K10: 3x3 / stride 2 / pad 1 max pooling, NHWC.  Forward keeps the winning tap (0..8, first
 // maximum in scan order like torch) as one byte per element; backward gathers.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+// BN = true: the input is a pre-BatchNorm tensor and z = relu(x*scale + shift) is applied on the fly
+// (stem fusion: the 112x112 activation is never written).  All nine taps are loaded with clamped
+// addresses before the first use (a branch per tap made hipcc wait for every load in turn).
+template <bool BN>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, bf16_t* __restrict__ out,
                                                          unsigned char* __restrict__ idx, int B, int H, int W, int C,
                                                          int Ho, int Wo) {
     const int cchunks = C >> 3;
     long long total = (long long)B * Ho * Wo * cchunks;
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        int cc = (int)(i % cchunks);
-        long long pix = i / cchunks;
-        int wo = (int)(pix % Wo);
-        long long t = pix / Wo;
-        int ho = (int)(t % Ho), b = (int)(t / Ho);
+        const unsigned iu = (unsigned)i;              // total < 2^32 (checked by the launcher)
+        int cc = (int)(iu % (unsigned)cchunks);
+        unsigned pix = iu / (unsigned)cchunks;
+        int wo = (int)(pix % (unsigned)Wo);
+        unsigned t = pix / (unsigned)Wo;
+        int ho = (int)(t % (unsigned)Ho), b = (int)(t / (unsigned)Ho);
+        bf16x8 v[9];
+        bool ok[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s;
+                ok[r * 3 + s] = (hi >= 0) & (hi < H) & (wi >= 0) & (wi < W);
+                int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+                v[r * 3 + s] = ld8<true>(x + (((long long)b * H + hc) * W + wc) * C + cc * 8);
+            }
+        float sc[8], sh[8];
+        if (BN) { load8f(scale + cc * 8, sc); load8f(shift + cc * 8, sh); }
         float best[8];
         unsigned char bi[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { best[e] = -3.0e38f; bi[e] = 0; }
         bool first = true;
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 9; ++k) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s;
-                if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((long long)b * H + hi) * W + wi) * C + cc * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float f = bf2f(v[e]);
-                    if (first || f > best[e]) { best[e] = f; bi[e] = (unsigned char)(r * 3 + s); }
-                }
-                first = false;
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(v[k][e]);
+                // BN: compare the bf16-rounded activations (ties resolve exactly as on the stored
+                // tensor of the unfused path); the ReLU is monotonic and is applied to the winner —
+                // where it changes the argmax (all taps <= 0) the gradient is masked anyway
+                if (BN) f = bf2f(f2bf(bn_affine(f, sc[e], sh[e])));
+                bool take = ok[k] & (first | (f > best[e]));
+                best[e] = take ? f : best[e];
+                bi[e] = take ? (unsigned char)k : bi[e];
             }
+            first = first & !ok[k];
+        }
         bf16x8 o;
         u32x2 packed = {0u, 0u};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            o[e] = f2bf(best[e]);
+            o[e] = f2bf(BN ? fmaxf(best[e], 0.f) : best[e]);
             packed[e >> 2] |= (unsigned)bi[e] << (8 * (e & 3));
         }
         *reinterpret_cast<bf16x8*>(out + (i << 3)) = o;
         if (idx) *reinterpret_cast<u32x2*>(idx + (i << 3)) = packed;
     }
+}
+
+// Gradient of the 3x3/2 max pool at input pixel (hi, wi), 8 channels: the up to four windows that
+// contain the pixel are read with clamped addresses (all loads first), a window contributes where
+// its stored argmax is this pixel's tap.  Rounded to bf16 like the tensor the unfused path wrote.
+__device__ __forceinline__ void pool_grad8(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ idx, int b,
+                                           int hi, int wi, int cc, int cchunks, int Ho, int Wo, float (&g)[8]) {
+    const int h0 = hi >> 1, h1 = (hi + 1) >> 1, w0 = wi >> 1, w1 = (wi + 1) >> 1;
+    bf16x8 d[4];
+    u32x2 pk[4];
+    bool ok[4];
+    unsigned tap[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ho = (k >> 1) ? h1 : h0, wo = (k & 1) ? w1 : w0;
+        ok[k] = (ho < Ho) & (wo < Wo) & (!(k >> 1) | (h1 != h0)) & (!(k & 1) | (w1 != w0));
+        const int hc = ho < Ho ? ho : Ho - 1, wc = wo < Wo ? wo : Wo - 1;
+        tap[k] = (unsigned)((hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1)));
+        const long long o = ((((long long)b * Ho + hc) * Wo + wc) * cchunks + cc) << 3;
+        pk[k] = *reinterpret_cast<const u32x2*>(idx + o);
+        d[k] = *reinterpret_cast<const bf16x8*>(dpool + o);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned w = (pk[k][e >> 2] >> (8 * (e & 3))) & 0xffu;
+            g[e] += (ok[k] & (w == tap[k])) ? bf2f(d[k][e]) : 0.f;
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = bf2f(f2bf(g[e]));
 }
 
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ idx,
@@ -393,37 +446,77 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const bf16_t* __restri
     long long total = (long long)B * H * W * cchunks;
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        int cc = (int)(i % cchunks);
-        long long pix = i / cchunks;
-        int wi = (int)(pix % W);
-        long long t = pix / W;
-        int hi = (int)(t % H), b = (int)(t / H);
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        int ho_lo = hi >> 1, ho_hi = (hi + 1) >> 1;   // windows ho with ho*2-1 <= hi <= ho*2+1
-        int wo_lo = wi >> 1, wo_hi = (wi + 1) >> 1;
-        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-            if (ho >= Ho) continue;
-            int r = hi - (ho * 2 - 1);
-            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                if (wo >= Wo) continue;
-                int s = wi - (wo * 2 - 1);
-                unsigned tap = (unsigned)(r * 3 + s);
-                long long o = ((((long long)b * Ho + ho) * Wo + wo) * cchunks + cc) << 3;
-                u32x2 pk = *reinterpret_cast<const u32x2*>(idx + o);
-                bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + o);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    unsigned w = (pk[e >> 2] >> (8 * (e & 3))) & 0xffu;
-                    if (w == tap) acc[e] += bf2f(d[e]);
-                }
-            }
-        }
+        const unsigned iu = (unsigned)i;
+        int cc = (int)(iu % (unsigned)cchunks);
+        unsigned pix = iu / (unsigned)cchunks;
+        int wi = (int)(pix % (unsigned)W);
+        unsigned t = pix / (unsigned)W;
+        int hi = (int)(t % (unsigned)H), b = (int)(t / (unsigned)H);
+        float g[8];
+        pool_grad8(dy, idx, b, hi, wi, cc, cchunks, Ho, Wo, g);
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
-        *reinterpret_cast<bf16x8*>(dx + (i << 3)) = o;
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(g[e]);
+        st8<true>(dx + (i << 3), o);
+    }
+}
+
+// Stem backward, fused: g = relu'(bn(y)) * maxpool_backward(dpool) is recomputed from the pooled
+// gradient and the argmax bytes instead of being read from a 112x112 tensor.
+//   pass 1 (APPLY = false): per-block partial sums  s1 = sum g, s2 = sum g*y   -> [G][2][C]
+//   pass 2 (APPLY = true):  dy = ca*g + cb*y + c0
+template <bool APPLY>
+__global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ idx,
+                                                              const bf16_t* __restrict__ y, const float* __restrict__ fcoef,
+                                                              const float* __restrict__ coef, float* __restrict__ partial,
+                                                              bf16_t* __restrict__ dy, int B, int H, int W, int C, int Ho, int Wo,
+                                                              long long rows_per_block) {
+    __shared__ float red[2][2048];
+    const int cchunks = C >> 3, rlanes = 256 / cchunks;
+    const int cc = threadIdx.x % cchunks, rl = threadIdx.x / cchunks;
+    const long long M = (long long)B * H * W;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s1[8], s2[8], sc[8], sh[8], ca[8], cb[8], c0[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    load8f(fcoef + cc * 8, sc); load8f(fcoef + C + cc * 8, sh);
+    if (APPLY) { load8f(coef + cc * 8, ca); load8f(coef + C + cc * 8, cb); load8f(coef + 2 * C + cc * 8, c0); }
+    // pixel coordinates of the first row, then stepped by `rlanes` pixels per trip
+    int wi, hi, b;
+    {
+        const unsigned ru = (unsigned)(r0 + rl);
+        wi = (int)(ru % (unsigned)W);
+        const unsigned t = ru / (unsigned)W;
+        hi = (int)(t % (unsigned)H); b = (int)(t / (unsigned)H);
+    }
+    for (long long r = r0 + rl; r < r1; r += rlanes) {
+        bf16x8 yv = ld8<true>(y + r * C + cc * 8);
+        float g[8];
+        pool_grad8(dpool, idx, b, hi, wi, cc, cchunks, Ho, Wo, g);
+        wi += rlanes;
+        while (wi >= W) { wi -= W; if (++hi == H) { hi = 0; ++b; } }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float yf = bf2f(yv[e]);
+            float ge = bn_affine(yf, sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+            if (APPLY) o[e] = f2bf(ca[e] * ge + cb[e] * yf + c0[e]);
+            else { s1[e] += ge; s2[e] += ge * yf; }
+        }
+        if (APPLY) st8<true>(dy + r * C + cc * 8, o);
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][threadIdx.x * 8 + e] = s1[e]; red[1][threadIdx.x * 8 + e] = s2[e]; }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * C; t += 256) {
+            int which = t / C, c = t - which * C;
+            float acc = 0.f;
+            for (int l = 0; l < rlanes; ++l) acc += red[which][(l * cchunks + (c >> 3)) * 8 + (c & 7)];
+            partial[((long long)blockIdx.x * 2 + which) * C + c] = acc;
+        }
     }
 }
 
@@ -720,13 +813,51 @@ extern "C" int ddl_bn_bwd_apply(const void* dz, const void* y, const void* z, co
     return ddl_launch_status();
 }
 
-extern "C" int ddl_maxpool3x3s2_fwd(const void* x, void* out, void* idx, int B, int H, int W, int C, hipStream_t stream) {
+static int maxpool_fwd_launch(const void* x, const void* scale, const void* shift, void* out, void* idx, int B, int H, int W,
+                              int C, hipStream_t stream) {
     CHK(x && out && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
     CHK(ddl_aligned16(x) && ddl_aligned16(out) && (!idx || (reinterpret_cast<uintptr_t>(idx) & 7) == 0), DDL_EALIGN);
+    CHK((scale == nullptr) == (shift == nullptr) && (!scale || (ddl_aligned16(scale) && ddl_aligned16(shift))), DDL_EINVAL);
     int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     long long total = (long long)B * Ho * Wo * (C >> 3);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)x,
-                       (bf16_t*)out, (unsigned char*)idx, B, H, W, C, Ho, Wo);
+    CHK((long long)B * H * W * (C >> 3) < (1LL << 32), DDL_EINVAL);
+    dim3 grid(ddl_stream_grid(total, 256)), block(256);
+    if (scale) hipLaunchKernelGGL(maxpool_fwd_kernel<true>, grid, block, 0, stream, (const bf16_t*)x, (const float*)scale,
+                                  (const float*)shift, (bf16_t*)out, (unsigned char*)idx, B, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<false>, grid, block, 0, stream, (const bf16_t*)x, (const float*)nullptr,
+                            (const float*)nullptr, (bf16_t*)out, (unsigned char*)idx, B, H, W, C, Ho, Wo);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_maxpool3x3s2_fwd(const void* x, void* out, void* idx, int B, int H, int W, int C, hipStream_t stream) {
+    return maxpool_fwd_launch(x, nullptr, nullptr, out, idx, B, H, W, C, stream);
+}
+
+// out = maxpool3x3s2(relu(x*scale + shift)) with x the pre-BatchNorm tensor (stem fusion)
+extern "C" int ddl_bn_relu_maxpool3x3s2_fwd(const void* x, const void* scale, const void* shift, void* out, void* idx, int B,
+                                            int H, int W, int C, hipStream_t stream) {
+    CHK(scale && shift && idx, DDL_EINVAL);
+    return maxpool_fwd_launch(x, scale, shift, out, idx, B, H, W, C, stream);
+}
+
+// Stem backward passes over the pre-BatchNorm tensor y [B,H,W,C]; dpool/idx are [B,Ho,Wo,C].
+// apply = 0: partial [G][2][C] sums (G = ddl_bn_bwd_blocks(B*H*W)); apply = 1: dy from coef [3][C].
+extern "C" int ddl_stem_pool_bn_bwd(const void* dpool, const void* idx, const void* y, const void* fcoef, const void* coef,
+                                    void* partial, void* dy, int B, int H, int W, int C, int G, int apply, hipStream_t stream) {
+    CHK(dpool && idx && y && fcoef && B > 0 && H > 0 && W > 0 && G > 0 && pow2_chunks_ok(C), DDL_EINVAL);
+    CHK(apply ? (coef && dy) : (partial != nullptr), DDL_EINVAL);
+    CHK(ddl_aligned16(dpool) && ddl_aligned16(y) && ddl_aligned16(fcoef) && (reinterpret_cast<uintptr_t>(idx) & 7) == 0 &&
+        (!coef || ddl_aligned16(coef)) && (!dy || ddl_aligned16(dy)), DDL_EALIGN);
+    int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    long long M = (long long)B * H * W;
+    CHK(M < (1LL << 32), DDL_EINVAL);
+    long long rpb = (M + G - 1) / G;
+    if (apply) hipLaunchKernelGGL(stem_pool_bn_bwd_kernel<true>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dpool,
+                                  (const unsigned char*)idx, (const bf16_t*)y, (const float*)fcoef, (const float*)coef,
+                                  (float*)nullptr, (bf16_t*)dy, B, H, W, C, Ho, Wo, rpb);
+    else hipLaunchKernelGGL(stem_pool_bn_bwd_kernel<false>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dpool,
+                            (const unsigned char*)idx, (const bf16_t*)y, (const float*)fcoef, (const float*)nullptr,
+                            (float*)partial, (bf16_t*)nullptr, B, H, W, C, Ho, Wo, rpb);
     return ddl_launch_status();
 }
 
@@ -735,6 +866,7 @@ extern "C" int ddl_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, i
     CHK(ddl_aligned16(dy) && ddl_aligned16(dx) && (reinterpret_cast<uintptr_t>(idx) & 7) == 0, DDL_EALIGN);
     int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     long long total = (long long)B * H * W * (C >> 3);
+    CHK(total < (1LL << 32), DDL_EINVAL);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)dy,
                        (const unsigned char*)idx, (bf16_t*)dx, B, H, W, C, Ho, Wo);
     return ddl_launch_status();

@@ -217,8 +217,14 @@ class ResNet(nn.Module):
             torch._foreach_add_(counters, 1)
             _NBT_BATCHED[0] = True
         try:
-            x = _cba(self.conv1, self.bn1, x)
-            x = ops.maxpool3x3s2(x)
+            if _has_hooks(self.conv1) or _has_hooks(self.bn1):
+                x = ops.maxpool3x3s2(_cba(self.conv1, self.bn1, x))
+            else:
+                conv, bn = self.conv1, self.bn1
+                if bn.training and not _NBT_BATCHED[0]:
+                    bn.num_batches_tracked += 1
+                x = ops.stem(x, conv.weight, conv.stride, conv.padding, bn.weight, bn.bias,
+                             bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps)
             x = self._trunk(x)
             return self.fc(ops.global_avgpool(x))
         finally:

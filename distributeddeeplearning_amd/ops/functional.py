@@ -121,6 +121,21 @@ def residual_block(x, units, downsample, training, momentum=0.1, eps=1e-5):
     return cur
 
 
+def stem(x, weight, stride, padding, gamma, beta, running_mean, running_var, training, momentum=0.1,
+         eps=1e-5):
+    """ResNet stem: conv -> BatchNorm -> ReLU -> 3x3/2 max pool (``HorovodTF/src/resnet_model.py:
+    256-266``).  In training mode on the HIP path this is one fused node (``hip_ops.StemFn``);
+    otherwise the composition of the three ops."""
+    if training and use_hip(x):
+        from . import hip_ops
+
+        if hip_ops.stem_supported(weight, stride, padding) and not x.requires_grad:
+            return hip_ops.stem(x, weight, gamma, beta, running_mean, running_var, momentum, eps)
+    y = conv_bn_act(x, weight, stride, padding, gamma, beta, running_mean, running_var, training,
+                    momentum, eps, True)
+    return maxpool3x3s2(y)
+
+
 def residual_chain(x, blocks, training, momentum=0.1, eps=1e-5):
     """Consecutive residual blocks, ``blocks`` = list of ``(units, downsample)`` as taken by
     :func:`residual_block`.  The intermediate activations are not exposed, which lets the HIP

@@ -588,6 +588,97 @@ class StemConvFn(Function):
         return None, dw, None
 
 
+class StemFn(Function):
+    """The whole ResNet stem in training mode as one node (``HorovodTF/src/resnet_model.py:
+    256-266``): 7x7/2 conv (K5) -> BatchNorm -> ReLU -> 3x3/2 max pool, with the BatchNorm apply,
+    the ReLU and the pooling in ONE pass over the conv output — the 112x112x64 activation (411 MB
+    at batch 256) is never written.  Backward recomputes the pool gradient from the pooled
+    gradient and the argmax bytes inside the two BatchNorm-backward passes."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, rmean, rvar, momentum, eps):
+        if x.dtype != _BF16:
+            x = x.to(_BF16)
+        B, C, H, W = x.shape
+        Kc = w.shape[0]
+        dev = x.device
+        xp = torch.empty((B, H, W + 8, 4), dtype=_BF16, device=dev)
+        K.stem_pack(x, xp)
+        wp = torch.zeros((Kc, 7, 8, 4), dtype=_BF16, device=dev)
+        wp[:, :, :7, :C] = w.permute(0, 2, 3, 1)
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        geom = (B, H, W + 1, 32, H * (W + 8) * 4, (W + 8) * 4, 4, xp.numel())
+        M = B * Ho * Wo
+        T = K.conv_tiles_m(M)
+        P = K._fold_slices(T) if T > 512 else 0
+        y = _empty_nhwc(B, Kc, Ho, Wo, dev)
+        coeffs = torch.empty((4, Kc), dtype=torch.float32, device=dev)
+        tmp = torch.empty(2 * T * Kc + 4 * P * Kc, dtype=torch.float32, device=dev)
+        st = tmp.data_ptr()
+        K.conv_igemm(xp, geom, wp, y, Kc, 7, 1, 2, 3, 0, 1, Ho, Wo, stats=st)
+        cb = coeffs.data_ptr()
+        K.bn_fwd_finalize(st, T, Kc, M, 128, gamma, beta, rmean, rvar, momentum, eps,
+                          cb, cb + 4 * Kc, cb + 8 * Kc, cb + 12 * Kc,
+                          work=st + 8 * T * Kc if P else None)
+        Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        out = _empty_nhwc(B, Kc, Hp, Wp, dev)
+        idx = torch.empty((B, Hp, Wp, Kc), dtype=torch.uint8, device=dev)
+        K.bn_relu_maxpool_fwd(y, cb + 8 * Kc, cb + 12 * Kc, out, idx, B, Ho, Wo, Kc)
+        ctx.save_for_backward(xp, w, y, idx, coeffs, gamma, beta)
+        ctx.geom = geom
+        ctx.cin = C
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xp, w, y, idx, coeffs, gamma, beta = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise K.KernelError("the stem does not provide a gradient for its input")
+        dout = _as_nhwc(dout)
+        B, Kc, Ho, Wo = y.shape
+        M = B * Ho * Wo
+        dev = y.device
+        G = K.bn_bwd_blocks(M)
+        P = K._fold_slices(G) if G > 512 else 0
+        tmp = torch.empty(3 * Kc + 2 * G * Kc + 2 * P * Kc, dtype=torch.float32, device=dev)
+        coef = tmp.data_ptr()
+        part = coef + 12 * Kc
+        wk = part + 8 * G * Kc if P else None
+        cb = coeffs.data_ptr()
+        fco = cb + 8 * Kc
+        K.stem_pool_bn_bwd(dout, idx, y, fco, None, part, None, B, Ho, Wo, Kc, G, False)
+        direct = _DIRECT["on"] and _direct_grad_ok(gamma) and _direct_grad_ok(beta) and \
+            gamma.grad.dtype == torch.float32 and beta.grad.dtype == torch.float32
+        if direct:
+            K.bn_bwd_finalize(part, G, Kc, M, gamma, cb, cb + 4 * Kc, gamma.grad, beta.grad, coef,
+                              accumulate=True, work=wk)
+            dg = db = None
+        else:
+            dgb = torch.empty((2, Kc), dtype=torch.float32, device=dev)
+            K.bn_bwd_finalize(part, G, Kc, M, gamma, cb, cb + 4 * Kc, dgb[0], dgb[1], coef, work=wk)
+            dg, db = dgb[0], dgb[1]
+        dy = torch.empty_like(y)
+        K.stem_pool_bn_bwd(dout, idx, y, fco, coef, None, dy, B, Ho, Wo, Kc,
+                           min(max(M // 64, 1), 16384), True)
+        if direct:
+            _notify(gamma)
+            _notify(beta)
+        dwp = torch.empty((Kc, 7, 8, 4), dtype=torch.float32, device=dev)
+        _wgrad_into(dy, xp, ctx.geom, dwp, Kc, 7, 1, 2, 3, 0, Ho, Wo)
+        dw = torch.empty_like(w)
+        dw.copy_(dwp[:, :, :7, :ctx.cin].permute(0, 3, 1, 2))
+        return None, dw, dg, db, None, None, None, None
+
+
+def stem_supported(weight, stride, padding):
+    return _is_stem(weight, stride, padding) and weight.shape[0] % 8 == 0 and \
+        bn_supported(weight.shape[0])
+
+
+def stem(x, weight, gamma, beta, rmean, rvar, momentum, eps):
+    return StemFn.apply(x, weight, gamma, beta, rmean, rvar, momentum, eps)
+
+
 def conv2d_stats(x, weight, stride, padding, want_stats):
     """(y, stats) where stats is the [tiles, 2, Cout] partial-sum tensor (or None)."""
     if _is_stem(weight, stride, padding):

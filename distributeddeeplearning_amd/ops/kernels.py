@@ -339,6 +339,20 @@ def maxpool_fwd(x, out, idx, B, H, W, C):
                                      stream()), "maxpool_fwd")
 
 
+def bn_relu_maxpool_fwd(x, scale, shift, out, idx, B, H, W, C):
+    """out = maxpool3x3s2(relu(x*scale + shift)) without materialising the activation."""
+    f = _fn("ddl_bn_relu_maxpool3x3s2_fwd", "ppppp iiii p")
+    check(f(x.data_ptr(), _p(scale), _p(shift), out.data_ptr(), idx.data_ptr(), B, H, W, C,
+            _raw_stream()), "bn_relu_maxpool_fwd")
+
+
+def stem_pool_bn_bwd(dpool, idx, y, fcoef, coef, partial, dy, B, H, W, C, G, apply):
+    """Fused stem backward pass over y [B,H,W,C]: reduce partials (apply=False) or dy (apply=True)."""
+    f = _fn("ddl_stem_pool_bn_bwd", "ppppppp iiiiii p")
+    check(f(dpool.data_ptr(), idx.data_ptr(), y.data_ptr(), _p(fcoef), _p(coef), _p(partial), _p(dy),
+            B, H, W, C, G, 1 if apply else 0, _raw_stream()), "stem_pool_bn_bwd")
+
+
 def maxpool_bwd(dy, idx, dx, B, H, W, C):
     check(lib().ddl_maxpool3x3s2_bwd(ptr(dy), ptr(idx), ptr(dx), _i32(B), _i32(H), _i32(W), _i32(C),
                                      stream()), "maxpool_bwd")

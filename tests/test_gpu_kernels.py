@@ -580,3 +580,36 @@ def test_bench_step_with_forced_rccl_collectives():
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["ops_backend"] == "hip"
     assert math.isfinite(rec["final_loss"]) and rec["final_loss"] < 12.0
+
+
+def test_fused_stem_matches_composition():
+    """StemFn (conv 7x7/2 -> BN -> ReLU -> maxpool in one node, activation never written) against
+    the same computation composed from the separate HIP ops."""
+    hip = _hip()
+    hip.reset_caches()
+    B, H, W = 5, 64, 96
+    x = torch.rand((B, 3, H, W), device=DEV).to(BF).contiguous(memory_format=CL)
+    w0 = (torch.randn((64, 3, 7, 7), device=DEV) / math.sqrt(147)).to(BF).contiguous(memory_format=CL)
+    g0 = torch.rand(64, device=DEV) + 0.5
+    b0 = torch.randn(64, device=DEV) * 0.2
+    gout = rand_nhwc(B, 64, 16, 24, seed=51)
+
+    def run(fused):
+        w = w0.clone().requires_grad_(True)
+        gamma, beta = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        if fused:
+            out = hip.stem(x, w, gamma, beta, rm, rv, 0.1, 1e-5)
+        else:
+            y, st = hip.conv2d_stats(x, w, 2, 3, True)
+            z = hip.batchnorm_act(y, gamma, beta, rm, rv, True, 0.1, 1e-5, True, None, stats=st)
+            out = hip.maxpool3x3s2(z)
+        out.backward(gout)
+        return out.detach(), w.grad, gamma.grad, beta.grad, rm, rv
+
+    a, b = run(False), run(True)
+    assert a[0].shape == (B, 64, 16, 24)
+    assert torch.equal(a[0], b[0])
+    for i in (1, 2, 3):
+        assert rms_relerr(b[i], a[i]) < 1e-2, i
+    assert torch.allclose(a[4], b[4]) and torch.allclose(a[5], b[5])
