@@ -115,8 +115,25 @@ def build_engine(force=False, jobs=8, verbose=True):
     return out
 
 
+def build_probes(force=False, verbose=True):
+    """Standalone HIP measurement programs under benchmarks/native (one executable per .hip)."""
+    outs = []
+    hipcc = _hipcc()
+    for s in sorted(glob.glob(os.path.join(ROOT, "benchmarks", "native", "*.hip"))):
+        out = s[:-4]
+        if force or _newer(out, [s]):
+            _run([hipcc, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fno-gpu-sanitize",
+                  "-Wno-unused-result", "-o", out, s])
+            if verbose:
+                print("[build] built", os.path.relpath(out, ROOT), flush=True)
+        outs.append(out)
+    return outs
+
+
 def build_all(force=False, jobs=8, verbose=True):
-    return build_kernels(force, jobs, verbose), build_engine(force, jobs, verbose)
+    libs = build_kernels(force, jobs, verbose), build_engine(force, jobs, verbose)
+    build_probes(force, verbose)
+    return libs
 
 
 if __name__ == "__main__":
