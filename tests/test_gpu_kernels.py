@@ -613,3 +613,36 @@ def test_fused_stem_matches_composition():
     for i in (1, 2, 3):
         assert rms_relerr(b[i], a[i]) < 1e-2, i
     assert torch.allclose(a[4], b[4]) and torch.allclose(a[5], b[5])
+
+
+def test_wgrad_side_stream_gives_identical_gradients():
+    """Weight gradients computed on the second HIP stream (direct-gradient mode) must equal the
+    single-stream result bit for bit, with the streams joined by the end of ``backward()``."""
+    from distributeddeeplearning_amd.models import resnet18
+    from distributeddeeplearning_amd.ops import functional as ops
+    from distributeddeeplearning_amd.parallel.bucket import GradArena
+
+    hip = _hip()
+    x = torch.rand((8, 3, 64, 64), device=DEV).to(BF).contiguous(memory_format=CL)
+    t = torch.randint(0, 10, (8,), device=DEV)
+
+    def run(side):
+        hip.reset_caches()
+        torch.manual_seed(11)
+        m = resnet18(num_classes=16).to_compute(torch.device(DEV), BF).train()
+        arena = GradArena(list(m.named_parameters()), 1 << 20, 1 << 20)
+        hip.set_wgrad_side_stream(side)
+        hip.set_direct_grads(True)
+        try:
+            for _ in range(2):  # second pass accumulates on top of the first
+                ops.softmax_cross_entropy(m(x), t).backward()
+        finally:
+            hip.set_direct_grads(False)
+            hip.set_wgrad_side_stream(True)
+        # no explicit synchronisation here: reading on the current stream must already be safe
+        return {n: p.grad.detach().float().clone() for n, p in m.named_parameters()}, arena
+
+    (a, _), (b, _) = run(False), run(True)
+    assert a.keys() == b.keys()
+    for n in a:
+        assert torch.equal(a[n], b[n]), n
