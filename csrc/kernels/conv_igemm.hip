@@ -356,15 +356,16 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 template <int BM, int BN, int BK>
 int launch_cfg(const IGemmParams& p, hipStream_t stream) {
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
+    static const int extra_lds = getenv("DDL_CONV_EXTRA_LDS") ? atoi(getenv("DDL_CONV_EXTRA_LDS")) : 0;  // occupancy probe
     if (p.stats && p.addend && !(p.ep_y && p.ep_mask)) return DDL_EINVAL;
-    if (p.ep_y && p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, true>), grid, block, 0, stream, p);
-    else if (p.ep_y && p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, false>), grid, block, 0, stream, p);
-    else if (p.ep_y) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 2, false>), grid, block, 0, stream, p);
-    else if (p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, true>), grid, block, 0, stream, p);
-    else if (p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, false>), grid, block, 0, stream, p);
-    else if (p.stats) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 1, false>), grid, block, 0, stream, p);
-    else if (p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, false>), grid, block, 0, stream, p);
+    if (p.ep_y && p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, true>), grid, block, extra_lds, stream, p);
+    else if (p.ep_y && p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, false>), grid, block, extra_lds, stream, p);
+    else if (p.ep_y) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 2, false>), grid, block, extra_lds, stream, p);
+    else if (p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, true>), grid, block, extra_lds, stream, p);
+    else if (p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, false>), grid, block, extra_lds, stream, p);
+    else if (p.stats) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 1, false>), grid, block, extra_lds, stream, p);
+    else if (p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, true>), grid, block, extra_lds, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, false>), grid, block, extra_lds, stream, p);
     return ddl_launch_status();
 }
 

@@ -1,7 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout -k 10 300 python -u bench.py --steps 20 --warmup 5 --optimizer lars 2>&1 | tail -1 | tee gpurun_out/bench_lars.log || exit 1
-timeout -k 10 300 python -u bench.py --steps 15 --warmup 5 --model resnet152 2>&1 | tail -1 | tee gpurun_out/bench_r152.log || exit 1
-timeout -k 10 300 python -u bench.py --steps 15 --warmup 5 --model resnet101 2>&1 | tail -1 | tee gpurun_out/bench_r101.log || exit 1
-timeout -k 10 300 python -u bench.py --steps 20 --warmup 5 --model resnet18 2>&1 | tail -1 | tee gpurun_out/bench_r18.log || exit 1
-timeout -k 10 300 python -u bench.py --steps 20 --warmup 5 --batch 512 2>&1 | tail -1 | tee gpurun_out/bench_b512.log || exit 1
+for x in 0 20000 45000; do
+  echo "== DDL_CONV_EXTRA_LDS=$x"
+  DDL_CONV_EXTRA_LDS=$x timeout -k 10 300 python -u benchmarks/kernel_bench.py --iters 20 --only c3,c4,c5,d1,d4,b4,a3,a4 2>&1 | grep -v amdgpu.ids | cut -c1-100 || exit 1
+done
