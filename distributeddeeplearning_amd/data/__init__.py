@@ -1,3 +1,3 @@
-from .fake import FakeData, FakeBatchIterator
+from .fake import FakeData, FakeBatchIterator, PrebatchedFakeStream
 from .sampler import ShardedSampler, EpochRandomSampler, get_sampler
 from .synthetic import DeviceSyntheticLoader

@@ -23,7 +23,7 @@ from torch.utils.data import Dataset
 
 from ..utils.config import IMAGENET_TRAIN_LEN
 
-__all__ = ["create_data", "create_labels", "FakeData", "FakeBatchIterator"]
+__all__ = ["create_data", "create_labels", "FakeData", "FakeBatchIterator", "PrebatchedFakeStream"]
 
 
 def create_data(batch_size, num_batches, dim, channels, rng, channels_last=False):
@@ -128,3 +128,97 @@ class FakeBatchIterator:
         if self.one_hot:
             y = torch.nn.functional.one_hot(y, self.n_classes).to(torch.float32)
         return x, y
+
+
+class PrebatchedFakeStream:
+    """The TF flavour's synthetic input (``imagenet_estimator_tf_horovod.py:295-345``): a
+    generator of ``num_batches`` (40) PRE-BATCHED ``[batch, 3, H, W]`` NCHW float32 arrays with
+    int labels, then ``shuffle(buffer)`` — of whole batches —, ``repeat()`` and ``prefetch(n)``.
+
+    ``length`` samples make an epoch (``len(stream)`` batches); iteration never ends when
+    ``repeat=True`` (tf.data ``repeat()``), else stops after one epoch.  ``prefetch`` batches are
+    produced ahead of the consumer by a background thread (the ``prefetch(_BUFFER)`` stage)."""
+
+    def __init__(self, batch_size=64, num_batches=40, dim=(224, 224), n_channels=3, n_classes=1000,
+                 length=None, shuffle_buffer=None, repeat=True, prefetch=2, seed=42):
+        self.batch_size, self.num_batches = int(batch_size), int(num_batches)
+        self.length = int(length if length is not None else batch_size * num_batches)
+        self.repeat = bool(repeat)
+        self.prefetch = max(int(prefetch), 0)
+        rng = np.random.default_rng(seed)
+        data = create_data(batch_size, num_batches, dim, n_channels, rng)
+        labels = create_labels(batch_size, num_batches, n_classes, rng)
+        shape = (self.num_batches, self.batch_size)
+        self._images = data.reshape(shape + data.shape[1:])
+        self._labels = labels.reshape(shape)
+        # tf.data shuffle(buffer_size): a buffer of that many ELEMENTS (batches here); the
+        # reference passes 40*batch, i.e. a buffer at least as large as the 40-element dataset
+        buf = self.num_batches if shuffle_buffer is None else int(shuffle_buffer)
+        self._buffer = max(min(buf, self.num_batches), 1)
+        self._rng = np.random.default_rng(seed + 1)
+
+    def __len__(self):
+        return int(np.ceil(self.length / float(self.batch_size)))
+
+    def _epoch_order(self):
+        """One pass over the 40 batches through a shuffle buffer of ``_buffer`` elements."""
+        pending = list(range(self.num_batches))
+        buf, out = [], []
+        while pending or buf:
+            while pending and len(buf) < self._buffer:
+                buf.append(pending.pop(0))
+            k = int(self._rng.integers(0, len(buf)))
+            out.append(buf.pop(k))
+        return out
+
+    def _generate(self):
+        produced = 0
+        per_epoch = len(self)
+        while True:
+            for b in self._epoch_order():
+                yield torch.from_numpy(self._images[b]), torch.from_numpy(self._labels[b])
+                produced += 1
+                if not self.repeat and produced >= per_epoch:
+                    return
+
+    def __iter__(self):
+        gen = self._generate()
+        if self.prefetch == 0:
+            return gen
+        import queue
+        import threading
+
+        q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+        done = object()
+
+        def worker():
+            try:
+                for item in gen:
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+            finally:
+                if not stop.is_set():
+                    q.put(done)
+
+        th = threading.Thread(target=worker, daemon=True)
+        th.start()
+
+        def consume():
+            try:
+                while True:
+                    item = q.get()
+                    if item is done:
+                        return
+                    yield item
+            finally:
+                stop.set()
+
+        return consume()
+

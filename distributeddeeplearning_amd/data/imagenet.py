@@ -28,7 +28,7 @@ from torch.utils.data import Dataset
 
 from ..utils.config import RGB_MEAN, RGB_SD
 
-__all__ = ["ImageFolder", "CsvImageDataset", "train_transform", "val_transform",
+__all__ = ["ImageFolder", "CsvImageDataset", "train_transform", "val_transform", "keras_train_transform", "keras_val_transform",
            "make_loader", "IMG_EXTENSIONS"]
 
 IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
@@ -100,6 +100,73 @@ def train_transform(size=224, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), n
         return _to_tensor(img, normalize)
 
     return apply
+
+
+_CAFFE_MEAN_BGR = (103.939, 116.779, 123.68)
+
+
+def _caffe_preprocess(img):
+    """``keras.applications.resnet50.preprocess_input``: RGB -> BGR, subtract the ImageNet channel
+    means on the 0-255 scale, no scaling; returns a float32 CHW tensor."""
+    import numpy as np
+
+    a = np.asarray(img.convert("RGB"), dtype=np.float32)[:, :, ::-1] - np.asarray(_CAFFE_MEAN_BGR, np.float32)
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+
+def keras_train_transform(size=224, width_shift=0.33, height_shift=0.33, zoom=0.5,
+                          horizontal_flip=True, preprocess="caffe", rng=None):
+    """The Keras flavour's training augmentation (``imagenet_keras_horovod.py:136-149``):
+    ``ImageDataGenerator(width_shift_range=0.33, height_shift_range=0.33, zoom_range=0.5,
+    horizontal_flip=True, preprocessing_function=resnet50.preprocess_input)`` on images resized
+    to ``size`` x ``size`` (``flow_from_directory(target_size=...)``): a random affine map —
+    zoom factors drawn independently per axis from [1-zoom, 1+zoom], shifts as fractions of the
+    image size — about the image centre with nearest-edge fill, then a coin-flip mirror."""
+    rng = rng or random
+
+    def apply(img):
+        Image = _pil()
+        img = img.convert("RGB").resize((size, size), Image.NEAREST)
+        zx, zy = rng.uniform(1 - zoom, 1 + zoom), rng.uniform(1 - zoom, 1 + zoom)
+        tx, ty = rng.uniform(-width_shift, width_shift) * size, rng.uniform(-height_shift, height_shift) * size
+        c = (size - 1) / 2.0
+        # output pixel (x, y) samples input (zx*(x-c) + c + tx, zy*(y-c) + c + ty)
+        coeffs = (zx, 0.0, c - zx * c + tx, 0.0, zy, c - zy * c + ty)
+        img = _affine_nearest_fill(img, coeffs, size)
+        if horizontal_flip and rng.random() < 0.5:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        return _caffe_preprocess(img) if preprocess == "caffe" else _to_tensor(img, True)
+
+    return apply
+
+
+def keras_val_transform(size=224, zoom=0.875, preprocess="caffe"):
+    """Validation generator of the Keras flavour (``imagenet_keras_horovod.py:122-133``): fixed
+    zoom 0.875 about the centre (a central 87.5 % crop scaled back up) + ``preprocess_input``."""
+
+    def apply(img):
+        Image = _pil()
+        img = img.convert("RGB").resize((size, size), Image.NEAREST)
+        c = (size - 1) / 2.0
+        img = _affine_nearest_fill(img, (zoom, 0.0, c - zoom * c, 0.0, zoom, c - zoom * c), size)
+        return _caffe_preprocess(img) if preprocess == "caffe" else _to_tensor(img, True)
+
+    return apply
+
+
+def _affine_nearest_fill(img, coeffs, size):
+    """Affine resampling with Keras' default ``fill_mode='nearest'`` (coordinates clamp to the
+    edge); PIL fills with a constant, so the image is edge-padded first and the map shifted."""
+    import numpy as np
+
+    Image = _pil()
+    pad = size  # shifts of +-0.33 and zoom 1.5 stay inside one image width of padding
+    a = np.asarray(img)
+    a = np.pad(a, ((pad, pad), (pad, pad), (0, 0)), mode="edge")
+    big = Image.fromarray(a)
+    a0, a1, a2, b0, b1, b2 = coeffs
+    shifted = (a0, a1, a2 + pad, b0, b1, b2 + pad)
+    return big.transform((size, size), Image.AFFINE, shifted, resample=Image.BILINEAR)
 
 
 def val_transform(resize=256, crop=224, normalize=True):

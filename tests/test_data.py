@@ -88,3 +88,57 @@ def test_csv_dataset(tmp_path):
     (tmp_path / "train.csv").write_text("filenames,num_id\na.png,7\n")
     ds = imagenet.CsvImageDataset(str(tmp_path / "train.csv"))
     assert len(ds) == 1 and ds[0][1] == 6  # labels are 1-based in the file (reference :98-132)
+
+
+def test_prebatched_fake_stream_tf_semantics():
+    """TF flavour (imagenet_estimator_tf_horovod.py:295-345): 40 pre-batched NCHW batches,
+    batch-level shuffle, repeat, prefetch."""
+    from distributeddeeplearning_amd.data import PrebatchedFakeStream
+
+    s = PrebatchedFakeStream(batch_size=4, num_batches=10, dim=(8, 8), length=40, prefetch=2)
+    assert len(s) == 10
+    it = iter(s)
+    seen = []
+    for _ in range(25):  # repeat(): runs past one epoch
+        x, y = next(it)
+        assert x.shape == (4, 3, 8, 8) and x.dtype == torch.float32 and y.shape == (4,)
+        assert 0.0 <= float(x.min()) and float(x.max()) < 1.0
+        seen.append(float(x.sum()))
+    it.close()
+    # every epoch is a permutation of the same 10 batches
+    assert sorted(seen[:10]) == sorted(seen[10:20])
+    assert seen[:10] != seen[10:20]
+    one = list(PrebatchedFakeStream(batch_size=4, num_batches=10, dim=(8, 8), length=22,
+                                    repeat=False, prefetch=0))
+    assert len(one) == 6  # ceil(22 / 4) batches, then stop
+    small_buf = PrebatchedFakeStream(batch_size=2, num_batches=6, dim=(4, 4), shuffle_buffer=1,
+                                     repeat=False, prefetch=0)
+    sums = [float(x.sum()) for x, _ in small_buf]
+    ref = [float(torch.from_numpy(small_buf._images[i]).sum()) for i in range(6)]
+    assert sums == ref  # buffer of one element = no shuffling
+
+
+def test_keras_transforms():
+    """Keras flavour augmentation (imagenet_keras_horovod.py:122-149): shift/zoom/flip affine with
+    nearest-edge fill and caffe-style preprocess_input."""
+    import random
+
+    from PIL import Image
+
+    from distributeddeeplearning_amd.data.imagenet import keras_train_transform, keras_val_transform
+
+    arr = (np.arange(64 * 48 * 3) % 251).astype(np.uint8).reshape(48, 64, 3)
+    img = Image.fromarray(arr)
+    t = keras_train_transform(size=32, rng=random.Random(3))(img)
+    assert t.shape == (3, 32, 32) and t.dtype == torch.float32
+    assert float(t.min()) >= -124.0 and float(t.max()) <= 255.0 - 103.0
+    # identity parameters reproduce resize + preprocess_input exactly (BGR order, mean-subtracted)
+    ident = keras_train_transform(size=32, width_shift=0.0, height_shift=0.0, zoom=0.0,
+                                  horizontal_flip=False)(img)
+    base = np.asarray(img.resize((32, 32), Image.NEAREST), dtype=np.float32)
+    want = base[:, :, ::-1] - np.array([103.939, 116.779, 123.68], dtype=np.float32)
+    assert np.allclose(ident.numpy(), want.transpose(2, 0, 1), atol=1e-3)
+    v = keras_val_transform(size=32)(img)
+    assert v.shape == (3, 32, 32)
+    # zoom 0.875 about the centre keeps the centre pixel neighbourhood in place
+    assert np.allclose(v.numpy()[:, 15:17, 15:17].mean(), ident.numpy()[:, 15:17, 15:17].mean(), atol=30)
