@@ -681,6 +681,29 @@ __global__ void __launch_bounds__(256) stem_pack_kernel(const bf16_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K21: rank of the label's logit within its row (0 = it is the maximum): one wave per row counts
+// the logits that beat it — larger, or equal with a lower index (the order torch.topk reports) —
+// so top-k correctness for every k is `rank < k` without sorting anything.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) label_rank_kernel(const bf16_t* __restrict__ logits, const long long* __restrict__ labels,
+                                                        int* __restrict__ rank, int B, int N, int ld) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const long long t = labels[row];
+    if (t < 0 || t >= N) { if (lane == 0) rank[row] = N; return; }
+    const bf16_t* p = logits + (long long)row * ld;
+    const float vt = bf2f(p[t]);
+    int cnt = 0;
+    for (int i = lane; i < N; i += 64) {
+        float v = bf2f(p[i]);
+        cnt += (v > vt) | ((v == vt) & (i < (int)t));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) rank[row] = cnt;
+}
+
 }  // namespace
 
 #define CHK(cond, code) do { if (!(cond)) return (code); } while (0)
@@ -931,3 +954,12 @@ extern "C" int ddl_stem_pack(const void* x, void* out, int B, int H, int W, int 
                        (bf16_t*)out, B, H, W, C, xs_b, xs_h, xs_w, xs_c);
     return ddl_launch_status();
 }
+
+// rank[row] = number of logits that precede the label's in top-k order; N for an invalid label
+extern "C" int ddl_label_rank(const void* logits, const void* labels, void* rank, int B, int N, int ld, hipStream_t stream) {
+    CHK(logits && labels && rank && B > 0 && N > 0 && ld >= N, DDL_EINVAL);
+    hipLaunchKernelGGL(label_rank_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const bf16_t*)logits,
+                       (const long long*)labels, (int*)rank, B, N, ld);
+    return ddl_launch_status();
+}
+

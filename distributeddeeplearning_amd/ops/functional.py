@@ -214,6 +214,12 @@ def softmax_cross_entropy(logits, target):
 def topk_correct(logits, target, ks=(1, 5)):
     """Number of samples whose label is within the top-k logits, for each k (eval metric;
     ``imagenet_keras_horovod.py:307`` accuracy + top_k_categorical_accuracy)."""
+    if use_hip(logits) and logits.dim() == 2 and logits.dtype == torch.bfloat16 and \
+            logits.stride(1) == 1:
+        from . import kernels as K
+
+        rank = K.label_rank(logits, target.contiguous())  # one wave per row, no sort
+        return [int((rank < k).sum().item()) for k in ks]
     maxk = max(ks)
     _, pred = logits.float().topk(maxk, dim=1)
     hit = pred.eq(target.view(-1, 1))

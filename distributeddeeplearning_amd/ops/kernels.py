@@ -372,6 +372,17 @@ def softmax_xent(logits, labels, loss_rows, dlogits, B, N, ldl, ldd, grad_scale)
           "softmax_xent")
 
 
+def label_rank(logits, labels):
+    """K21: per-row rank (int32) of the label's logit in top-k order; top-k hit = rank < k."""
+    B, N = logits.shape
+    assert logits.dtype == torch.bfloat16 and logits.stride(1) == 1 and labels.dtype == torch.int64
+    rank = torch.empty(B, dtype=torch.int32, device=logits.device)
+    f = _fn("ddl_label_rank", "ppp iii p")
+    check(f(logits.data_ptr(), labels.data_ptr(), rank.data_ptr(), B, N, logits.stride(0),
+            _raw_stream()), "label_rank")
+    return rank
+
+
 def bias_add_(y, bias, M, N):
     check(lib().ddl_bias_add(ptr(y), ptr(bias), _i64(M), _i32(N), stream()), "bias_add")
 

@@ -646,3 +646,26 @@ def test_wgrad_side_stream_gives_identical_gradients():
     assert a.keys() == b.keys()
     for n in a:
         assert torch.equal(a[n], b[n]), n
+
+
+def test_topk_label_rank_kernel():
+    """K21: top-1 / top-5 counts from the label-rank kernel against torch.topk (ties included)."""
+    from distributeddeeplearning_amd.ops import functional as ops
+
+    _hip()
+    torch.manual_seed(4)
+    logits = (torch.randn(301, 1000, device=DEV) * 2).to(BF)
+    logits[:, 100:110] = logits[:, 100:101]  # runs of exactly equal values
+    target = torch.randint(0, 1000, (301,), device=DEV)
+    target[:40] = logits[:40].float().argmax(dim=1)
+    target[40:80] = torch.randint(100, 110, (40,), device=DEV)
+    got = ops.topk_correct(logits, target, ks=(1, 5, 10))
+    _, pred = logits.float().topk(10, dim=1)
+    hit = pred.eq(target.view(-1, 1))
+    want = [int(hit[:, :k].any(dim=1).sum()) for k in (1, 5, 10)]
+    # torch.topk's order among exactly equal values is not specified; the kernel breaks ties by
+    # index, so allow the tied rows to differ
+    tied = int(((target >= 100) & (target < 110)).sum())
+    assert got[0] >= 40
+    for g, w in zip(got, want):
+        assert abs(g - w) <= tied, (got, want)
