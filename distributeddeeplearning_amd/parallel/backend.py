@@ -209,6 +209,12 @@ def comm():
     return _S.comm
 
 
+def trivial() -> bool:
+    """True when collectives are local no-ops: one rank and no communicator (a one-rank job run
+    with ``HVD_FORCE_COLLECTIVES=1`` does have one and exercises the real code path)."""
+    return _S.size == 1 and _S.comm is None
+
+
 def engine_name() -> str:
     return _S.engine
 
@@ -232,5 +238,5 @@ def engine_config() -> EngineConfig:
 
 def barrier() -> None:
     _require()
-    if _S.size > 1:
+    if _S.comm is not None:
         _S.comm.barrier()

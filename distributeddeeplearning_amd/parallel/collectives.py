@@ -80,7 +80,7 @@ def _resolve_op(average, op):
 
 def _check_consistency(kind, tensor, name):
     """Debug-mode guard: all ranks must submit the same (kind, name, shape, dtype)."""
-    if not _b.engine_config().debug or _b.size() == 1 or _b.comm().checks_consistency:
+    if not _b.engine_config().debug or _b.trivial() or _b.comm().checks_consistency:
         return
     sig = "%s|%s|%s|%s" % (kind, name, tuple(tensor.shape), tensor.dtype)
     digest = int.from_bytes(hashlib.sha1(sig.encode()).digest()[:6], "big")
@@ -123,7 +123,7 @@ def allreduce_async_(tensor, average=None, name=None, op=None, compression=Compr
     op = _resolve_op(average, op)
     name = name or "allreduce.noname.%d" % next(_auto_names)
     world = _b.size()
-    if world == 1:
+    if _b.trivial():
         return _register(None, tensor, None, name)
     _check_consistency("allreduce", tensor, name)
     _tl.begin(name, "ALLREDUCE")
@@ -181,7 +181,7 @@ def allgather_async(tensor, name=None):
     """Concatenate along dim 0 across ranks; first dimensions may differ between ranks."""
     name = name or "allgather.noname.%d" % next(_auto_names)
     world = _b.size()
-    if world == 1:
+    if _b.trivial():
         return _register(None, tensor.detach().clone(), None, name)
     if tensor.dim() == 0:
         raise ValueError("allgather needs at least one dimension")
@@ -218,7 +218,7 @@ def allgather(tensor, name=None):
 
 def broadcast_async_(tensor, root_rank, name=None):
     name = name or "broadcast.noname.%d" % next(_auto_names)
-    if _b.size() == 1:
+    if _b.trivial():
         return _register(None, tensor, None, name)
     if not 0 <= root_rank < _b.size():
         raise ValueError("root_rank %d out of range" % root_rank)
@@ -281,12 +281,12 @@ def poll(handle) -> bool:
 
 def broadcast_object(obj, root_rank=0, name=None):
     """Broadcast an arbitrary picklable object through the control plane."""
-    if _b.size() == 1:
+    if _b.trivial():
         return obj
     return _b.comm().broadcast_object(obj, root_rank, _b.rank())
 
 
 def allgather_object(obj, name=None):
-    if _b.size() == 1:
+    if _b.trivial():
         return [obj]
     return _b.comm().all_gather_object(obj, _b.size())

@@ -28,7 +28,7 @@ __all__ = ["broadcast_parameters", "broadcast_optimizer_state", "metric_average"
 
 def coalesced_broadcast_(tensors, root_rank=0, name="coalesced"):
     """Broadcast a list of tensors in place using one flat buffer per (dtype, device)."""
-    if _b.size() == 1:
+    if _b.trivial():
         return
     groups = collections.OrderedDict()
     for t in tensors:
@@ -111,7 +111,7 @@ def broadcast_optimizer_state(optimizer, root_rank=0):
     equal to the root's.  Works whether or not non-root ranks have materialised their state:
     the root ships the structure through the control plane, tensors go coalesced over the
     data plane."""
-    if _b.size() == 1:
+    if _b.trivial():
         return
     is_root = _b.rank() == root_rank
     tensors = []

@@ -669,3 +669,47 @@ def test_topk_label_rank_kernel():
     assert got[0] >= 40
     for g, w in zip(got, want):
         assert abs(g - w) <= tied, (got, want)
+
+
+def test_forced_rccl_collectives_api_surface():
+    """Every hvd.* collective on a real one-rank RCCL communicator (``HVD_FORCE_COLLECTIVES=1``):
+    broadcast_parameters / optimizer state, allreduce (average, max), allgather, broadcast,
+    object broadcast, barrier — the calls the N>1 bench makes before and after its timed loop."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import os, torch
+import distributeddeeplearning_amd.torch as hvd
+from distributeddeeplearning_amd.models import resnet18
+from distributeddeeplearning_amd.optim import FusedSGD
+hvd.init()
+assert hvd.size() == 1 and hvd.rank() == 0
+dev = torch.device('cuda', torch.cuda.current_device())
+m = resnet18(num_classes=8).to_compute(dev, torch.bfloat16)
+before = {k: v.clone() for k, v in m.state_dict().items()}
+hvd.broadcast_parameters(m.state_dict(), root_rank=0)
+for k, v in m.state_dict().items():
+    assert torch.equal(v, before[k]), k
+opt = FusedSGD(m.named_parameters(), lr=0.1, momentum=0.9)
+hvd.broadcast_optimizer_state(opt, root_rank=0)
+t = torch.arange(10, dtype=torch.float32, device=dev)
+assert torch.equal(hvd.allreduce(t, name='a'), t)
+assert torch.equal(hvd.allreduce(t.double(), op=hvd.Max, name='b'), t.double())
+assert torch.equal(hvd.allgather(t.view(5, 2), name='c'), t.view(5, 2))
+assert torch.equal(hvd.broadcast(t.to(torch.bfloat16), 0, name='d'), t.to(torch.bfloat16))
+h = hvd.allreduce_async_(t.clone(), name='e'); hvd.synchronize(h)
+assert hvd.broadcast_object({'epoch': 3}, 0) == {'epoch': 3}
+hvd.barrier()
+hvd.shutdown()
+print('OK')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HVD_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534",
+               HVD_DEBUG="1", PYTHONPATH=root)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                         timeout=300, cwd=root)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-3000:]
