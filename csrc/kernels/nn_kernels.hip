@@ -724,9 +724,12 @@ extern "C" int ddl_bn_stats_partial(const void* y, void* partial, long long M, i
 
 // workspace (doubles) needed by ddl_bn_fwd_finalize for T tiles of C channels
 extern "C" long long ddl_bn_fold_slices(int T) {
+    // ~64 tiles per slice, at most 32 slices — 128 for the longest tables (the stem's 25088 tiles
+    // of 64 channels gave a 1 x 32 grid that took 33 us)
     int P = T / 64;
     if (P < 1) P = 1;
-    if (P > 32) P = 32;
+    const int cap = T >= 16384 ? 128 : 32;
+    if (P > cap) P = cap;
     return P;
 }
 
