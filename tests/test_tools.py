@@ -105,3 +105,79 @@ def test_create_resources_init_writes_cluster_and_env(tmp_path, monkeypatch):
                                   "--out", str(out)]) == 0
     cl = json.loads(out.read_text())
     assert cl["nodes"] == ["a", "b", "c"] and cl["gpus_per_node"] == 4 and cl["mounts"]["train"] == "/d/train"
+
+
+def _write_csv(path, header, rows):
+    import csv
+
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_ALL)
+        w.writerow(header)
+        w.writerows(rows)
+
+
+def test_pmc_summary_condenses_counter_csv(tmp_path):
+    """scripts/pmc_summary.py: rocprofv3 --pmc counter_collection.csv -> markdown table."""
+    import subprocess
+    import sys
+
+    hdr = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id",
+           "Grid_Size", "Kernel_Id", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size",
+           "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name",
+           "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    k = "void (anonymous namespace)::conv_igemm_kernel<128, 128, 32, 1, false>((anonymous namespace)::IGemmParams)"
+    base = [1, 1, "Agent 1", 1, 9, 9, 256 * 784, 3, k, 256, 38912, 0, 64, 0, 48]
+    rows = []
+    for disp in (1, 2):
+        for name, val in (("SQ_WAVES", 3136), ("SQ_WAVE_CYCLES", 1e8), ("SQ_INSTS_MFMA", 3.6e6),
+                          ("SQ_VALU_MFMA_BUSY_CYCLES", 5.76e7), ("SQ_WAIT_INST_ANY", 3e7),
+                          ("SQ_LDS_BANK_CONFLICT", 3e5)):
+            r = list(base)
+            r[1] = disp
+            rows.append(r + [name, val, 1000, 91000])
+    rows.append([1, 3, "Agent 1", 1, 9, 9, 1024, 4, "some_torch_kernel", 256, 0, 0, 8, 0, 8,
+                 "SQ_WAVES", 4, 0, 10])
+    _write_csv(str(tmp_path / "run" / "sq" / "vm" / "1_counter_collection.csv"), hdr, rows)
+    _write_csv(str(tmp_path / "run" / "fetch" / "vm" / "2_counter_collection.csv"), hdr,
+               [base + ["FETCH_SIZE", 20480.0, 1000, 91000]])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_summary.py"),
+                          str(tmp_path / "run")], capture_output=True, text=True, check=True).stdout
+    line = [l for l in out.splitlines() if l.startswith("| conv_igemm_kernel")]
+    assert len(line) == 1 and "some_torch_kernel" not in out
+    cells = [c.strip() for c in line[0].strip("|").split("|")]
+    head = [c.strip() for c in [l for l in out.splitlines() if l.startswith("| kernel")][0].strip("|").split("|")]
+    rec = dict(zip(head, cells))
+    assert rec["blocks"] == "784" and rec["dur_us"] == "90"
+    assert abs(float(rec["mfma_util%"]) - 100 * 5.76e7 / (90 * 2400 * 1024)) < 0.1
+    assert abs(float(rec["TF/s"]) - 3.6e6 * 16384 / 90 / 1e6) < 1
+    assert rec["hbm_MiB"] == "20.0"
+
+
+def test_trace_gaps_reports_streams_and_gaps(tmp_path):
+    """scripts/trace_gaps.py: per-stream busy time and main-stream gaps of the last step."""
+    import subprocess
+    import sys
+
+    hdr = ["Kind", "Agent_Id", "Queue_Id", "Stream_Id", "Thread_Id", "Dispatch_Id", "Kernel_Id",
+           "Kernel_Name", "Correlation_Id", "Start_Timestamp", "End_Timestamp", "LDS_Block_Size",
+           "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X",
+           "Workgroup_Size_Y", "Workgroup_Size_Z", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"]
+
+    def row(q, s, name, a, b):
+        return ["KERNEL_DISPATCH", "Agent 1", q, s, 1, 1, 1, name, 1, a, b, 0, 0, 8, 0, 8, 256, 1, 1, 1024, 1, 1]
+
+    rows = []
+    t = 0
+    for step in range(3):
+        base = step * 10_000_000
+        rows.append(row(1, 0, "conv_igemm_kernel<a>", base, base + 100_000))
+        rows.append(row(1, 0, "bn_apply", base + 150_000, base + 250_000))       # 50 us gap
+        rows.append(row(2, 1, "conv_wgrad_kernel<a>", base + 120_000, base + 400_000))
+        rows.append(row(1, 0, "fused_sgd_kernel<true, true>", base + 5_000_000, base + 5_080_000))
+    path = str(tmp_path / "1_kernel_trace.csv")
+    _write_csv(path, hdr, rows)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "trace_gaps.py"), path],
+                         capture_output=True, text=True, check=True).stdout
+    assert "queue 1 stream 0: 3 kernels" in out and "queue 2 stream 1: 1 kernels" in out
+    assert "50.0 us" in out and "conv_igemm_kernel<a> -> bn_apply" in out
