@@ -22,7 +22,6 @@ MI355X layout: activations are NHWC (``channels_last``) bf16, conv weights are s
 """
 from __future__ import annotations
 
-import math
 
 import torch
 import torch.nn as nn

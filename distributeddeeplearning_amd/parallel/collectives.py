@@ -23,7 +23,6 @@ import threading
 import time
 
 import torch
-import torch.distributed as dist
 
 from . import backend as _b
 from .compression import Compression

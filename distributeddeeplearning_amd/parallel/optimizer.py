@@ -23,10 +23,8 @@ from __future__ import annotations
 
 import hashlib
 import os
-import time
 
 import torch
-import torch.distributed as dist
 
 from . import backend as _b
 from . import timeline as _tl

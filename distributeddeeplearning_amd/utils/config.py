@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import argparse
 import os
-from dataclasses import dataclass, field, fields
+from dataclasses import dataclass, fields
 from typing import Optional
 
 __all__ = ["str_to_bool", "env_int", "env_float", "env_bool", "env_str", "TrainConfig",
