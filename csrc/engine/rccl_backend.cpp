@@ -38,14 +38,18 @@ struct Rccl {
     std::string err;
 } g;
 
+// an event from the recycle pool (or a new one); nullptr when HIP cannot create one
 hipEvent_t get_event() {
-    if (!g.pool.empty()) {
-        hipEvent_t e = g.pool.back();
-        g.pool.pop_back();
-        return e;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (!g.pool.empty()) {
+            hipEvent_t e = g.pool.back();
+            g.pool.pop_back();
+            return e;
+        }
     }
     hipEvent_t e = nullptr;
-    hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     return e;
 }
 
@@ -98,18 +102,19 @@ int ddl_rccl_init(int rank, int size, int device, int timeout_ms) {
     ncclResult_t r = ncclCommInitRank(&g.comm, size, id, rank);
     if (r != ncclSuccess) { fail("ncclCommInitRank", r); g.comm = nullptr; return -1; }
     int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; }  // hi = numerically lowest = highest priority
     if (hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, hi) != hipSuccess) { g.err = "stream create failed"; return -1; }
     return 0;
 }
 
 void ddl_rccl_shutdown() {
     if (!g.comm) return;
-    hipStreamSynchronize(g.stream);
+    // teardown: nothing useful can be done with a failure here
+    (void)hipStreamSynchronize(g.stream);
     ncclCommDestroy(g.comm);
-    hipStreamDestroy(g.stream);
-    for (auto& kv : g.done) hipEventDestroy(kv.second);
-    for (auto e : g.pool) hipEventDestroy(e);
+    (void)hipStreamDestroy(g.stream);
+    for (auto& kv : g.done) (void)hipEventDestroy(kv.second);
+    for (auto e : g.pool) (void)hipEventDestroy(e);
     g.done.clear(); g.pool.clear();
     g.comm = nullptr; g.stream = nullptr;
 }
@@ -119,7 +124,7 @@ int ddl_rccl_group_end() { return ncclGroupEnd() == ncclSuccess ? 0 : -1; }
 
 static long long finish_launch(const char* name) {
     hipEvent_t done = get_event();
-    hipEventRecord(done, g.stream);
+    if (!done || hipEventRecord(done, g.stream) != hipSuccess) { g.err = "completion event could not be recorded"; return -1; }
     std::lock_guard<std::mutex> lk(g.mu);
     long long h = g.next++;
     g.done[h] = done;
@@ -129,6 +134,7 @@ static long long finish_launch(const char* name) {
 
 static bool gate(void* producer_stream) {
     hipEvent_t ready = get_event();
+    if (!ready) return false;
     bool ok = hipEventRecord(ready, (hipStream_t)producer_stream) == hipSuccess &&
               hipStreamWaitEvent(g.stream, ready, 0) == hipSuccess;
     std::lock_guard<std::mutex> lk(g.mu);

@@ -45,10 +45,6 @@ struct IGemmParams {
     const bf16_t* ep_mask;   // EPI 3: ReLU output; the result is zeroed where it is <= 0
 };
 
-__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
-}
-
 // byte offset of 16-byte chunk `ch` of row `row` in a [rows][BK] bf16 LDS tile (swizzled)
 template <int BK>
 __device__ __forceinline__ int lds_off(int row, int ch) {

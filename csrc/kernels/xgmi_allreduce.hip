@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) xgmi_allreduce_kernel(const XgmiParams p)
     const int n = p.nranks;
     const int r = p.simulate ? (int)blockIdx.y : p.rank;
     // 1. announce "my buffer holds this step's input" to every rank (including myself)
-    if (blockIdx.x == 0 && threadIdx.x < n) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < n) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope
         __hip_atomic_store(p.flags[threadIdx.x] + r, p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) xgmi_allreduce_kernel(const XgmiParams p)
     }
     __syncthreads();
     if (!ok_s) return;
-    if (threadIdx.x < n)
+    if ((int)threadIdx.x < n)
         __hip_atomic_store(p.flags[threadIdx.x] + 8 + r, p.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // 4. the kernel may only complete once every rank's writes into MY buffer have landed
     //    (two-shot) / every rank has finished reading my buffer (one-shot)
