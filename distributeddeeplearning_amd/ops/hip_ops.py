@@ -181,9 +181,25 @@ def _direct_grad_ok(p):
         g.stride() == p.stride() and g.data_ptr() % 16 == 0
 
 
+# Inside a fused block's backward, readiness notifications are held back until the next kernel of
+# the dependent chain has been issued: a notification may launch a gradient collective (~50-100 us
+# of host time), and in the late layers the host is what the main stream waits for.
+_DEFER = {"on": False, "items": []}
+
+
 def _notify(p):
+    if _DEFER["on"]:
+        _DEFER["items"].append(p)
+        return
     for fn in _grad_listeners:
         fn(p)
+
+
+def _flush_notifications():
+    items, _DEFER["items"] = _DEFER["items"], []
+    for p in items:
+        for fn in _grad_listeners:
+            fn(p)
 
 
 # ---- raw (autograd-free) building blocks -------------------------------------------------------
@@ -823,6 +839,18 @@ class ResidualBlockFn(Function):
             base = 2 + 5 * unit
             grads[base], grads[base + 1], grads[base + 2] = dw, dg, db
 
+        _DEFER["on"] = True
+        try:
+            return ResidualBlockFn._backward_body(ctx, saved, x, ys, zs, cs, groups, grads, dout, put)
+        finally:
+            _DEFER["on"] = False
+            _flush_notifications()
+
+    @staticmethod
+    def _backward_body(ctx, saved, x, ys, zs, cs, groups, grads, dout, put):
+        units, strides, pads, has_ds, ds_stride, training, momentum, eps = ctx.cfg[:8]
+        premask_in, grad_premasked = ctx.cfg[8], ctx.cfg[9]
+        link_in, link_out = (ctx.cfg[10], ctx.cfg[11]) if len(ctx.cfg) > 11 else (None, None)
         dz = dout
         g_short = None
         # BatchNorm-backward partials produced by the previous dgrad's epilogue (for the last
@@ -849,6 +877,7 @@ class ResidualBlockFn(Function):
                                                cs[i - 1].data_ptr() + 8 * inp.shape[1])
                 else:
                     dz, fused = _conv_dgrad(dy, w, inp.shape, strides[i], pads[i]), None
+                _flush_notifications()  # the chain's next kernel is queued: now talk to the exchange
             else:
                 addend, sub2 = g_short, False
                 if has_ds:

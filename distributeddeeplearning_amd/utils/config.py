@@ -153,10 +153,11 @@ class TrainConfig:
 class EngineConfig:
     """Gradient-exchange engine tunables."""
 
-    # bytes per bucket cap.  8 MB: ResNet-50's 51 MB of bf16 gradients become 7 buckets; the last one
-    # (layer3.1 .. conv1, 6 MB) is the only exchange that cannot overlap with backward, and on
-    # point-to-point xGMI links a ring all-reduce of 8 MB already runs near its large-message rate
-    fusion_threshold: int = 8 * 1024 * 1024
+    # bytes per bucket cap.  Measured with a one-rank RCCL communicator (HVD_FORCE_COLLECTIVES=1,
+    # profiles/r1_notes.md): every extra bucket costs ~0.065 ms per step (collective launch on the
+    # host while the late layers' short kernels wait for it), so 32 MB (3 bf16 buckets + 1 fp32 for
+    # ResNet-50; the un-overlappable tail is the last 11.5 MB) beats 8 MB (7 + 1, 6 MB tail)
+    fusion_threshold: int = 32 * 1024 * 1024
     first_bucket_bytes: int = 8 * 1024 * 1024  # small first bucket: comm starts early in backward
     comm_dtype: str = "auto"  # auto = gradient dtype | bf16 | fp32
     backend: str = "auto"  # auto | rccl | gloo
@@ -173,7 +174,7 @@ class EngineConfig:
     @classmethod
     def from_env(cls) -> "EngineConfig":
         return cls(
-            fusion_threshold=env_int("HVD_FUSION_THRESHOLD", 8 * 1024 * 1024,
+            fusion_threshold=env_int("HVD_FUSION_THRESHOLD", 32 * 1024 * 1024,
                                      "HOROVOD_FUSION_THRESHOLD"),
             first_bucket_bytes=env_int("HVD_FIRST_BUCKET_BYTES", 8 * 1024 * 1024),
             comm_dtype=env_str("HVD_COMM_DTYPE", "auto"),

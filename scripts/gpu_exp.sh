@@ -1,6 +1,6 @@
 #!/bin/bash
-mkdir -p gpurun_out
-for x in 0 20000 45000; do
-  echo "== DDL_CONV_EXTRA_LDS=$x"
-  DDL_CONV_EXTRA_LDS=$x timeout -k 10 300 python -u benchmarks/kernel_bench.py --iters 20 --only c3,c4,c5,d1,d4,b4,a3,a4 2>&1 | grep -v amdgpu.ids | cut -c1-100 || exit 1
+for t in 134217728 33554432 16777216 8388608 4194304; do
+  echo "== HVD_FUSION_THRESHOLD=$t"
+  HVD_FORCE_COLLECTIVES=1 HVD_FUSION_THRESHOLD=$t HVD_FIRST_BUCKET_BYTES=$t timeout -k 10 200 python -u bench.py 2>&1 | tail -1 | grep -o "ms_per_step\": [0-9.]*" | tr '\n' ' ' || exit 1
+  echo
 done
