@@ -288,3 +288,17 @@ extern "C" int ddl_nchw_to_nhwc_norm(const void* in, void* out, long long B, int
         return DDL_EINVAL;
     return ddl_launch_status();
 }
+
+// Stream helpers for the Python side (created through the same HIP runtime instance the kernels
+// are launched with; torch.cuda.ExternalStream wraps the handle).
+extern "C" int ddl_stream_priority_range(int* least, int* greatest) {
+    return hipDeviceGetStreamPriorityRange(least, greatest) == hipSuccess ? DDL_OK : DDL_ELAUNCH;
+}
+
+extern "C" int ddl_stream_create(int priority, void** out) {
+    hipStream_t s = nullptr;
+    if (!out || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) return DDL_ELAUNCH;
+    *out = (void*)s;
+    return DDL_OK;
+}
+

@@ -83,31 +83,20 @@ def _p(t):
     return t if t.__class__ is int else t.data_ptr()
 
 
-_hip_rt = None
-
-
-def _hip():
-    """libamdhip64 (already loaded by torch) for the few runtime calls torch does not expose."""
-    global _hip_rt
-    if _hip_rt is None:
-        _hip_rt = ctypes.CDLL("libamdhip64.so")
-    return _hip_rt
-
-
 def stream_priority_range():
     """(least, greatest) stream priority of the current device; numerically lower = higher."""
     least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-    check(_hip().hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)),
+    check(lib().ddl_stream_priority_range(ctypes.byref(least), ctypes.byref(greatest)),
           "hipDeviceGetStreamPriorityRange")
     return least.value, greatest.value
 
 
 def create_stream(priority: int) -> int:
     """A non-blocking HIP stream of the given priority on the current device (never destroyed:
-    process lifetime); returns the raw handle for ``torch.cuda.ExternalStream``."""
+    process lifetime); returns the raw handle for ``torch.cuda.ExternalStream``.  Created inside
+    the kernel library so that it belongs to the HIP runtime instance the launches go through."""
     h = ctypes.c_void_p()
-    check(_hip().hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority)),
-          "hipStreamCreateWithPriority")
+    check(lib().ddl_stream_create(ctypes.c_int(priority), ctypes.byref(h)), "hipStreamCreateWithPriority")
     return h.value
 
 
