@@ -50,7 +50,7 @@ class _ArenaOptimizer(Optimizer):
             raise ValueError("arena optimizers use a single parameter group")
         cfg = engine_config or EngineConfig.from_env()
         self.arena = GradArena(named, cfg.first_bucket_bytes, cfg.fusion_threshold,
-                               flatten_params=True)
+                               flatten_params=True, tail_bucket_bytes=cfg.tail_bucket_bytes)
         flt = weight_decay_filter or default_weight_decay_filter
         self._names = {id(p): n for n, p in named}
         self.momentum_buf = {}

@@ -72,12 +72,17 @@ class ArenaPlan:
 
 
 def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_bytes: int,
-                reverse: bool = True) -> dict:
+                reverse: bool = True, tail_bucket_bytes: int = 0) -> dict:
     """Plan one arena per dtype.
 
     ``entries`` is a sequence of ``(name, shape, dtype)`` in registration (forward) order.
     Returns ``{dtype: ArenaPlan}``.  A tensor is never split across buckets; a tensor larger
     than the cap gets a bucket of its own.
+
+    ``tail_bucket_bytes`` > 0 closes the bucket before the last ``tail_bucket_bytes`` of the
+    arena: those tensors (the first layers) only become ready at the very end of backward, and
+    whatever shares their bucket cannot be exchanged before — with a small tail bucket the large
+    one in front of it overlaps with the stem's backward instead of waiting for it.
     """
     by_dtype: dict = {}
     order = list(enumerate(entries))
@@ -93,13 +98,27 @@ def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_by
         segments, buckets = [], []
         cursor = 0
         cur = Bucket(0, 0, 0)
-        for idx, name, shape in items:
+        tail_start = None
+        sizes = []
+        for _, _, shape in items:
+            sz = esize
+            for d in shape:
+                sz *= int(d)
+            sizes.append(sz)
+        if tail_bucket_bytes > 0 and sum(sizes) > 4 * tail_bucket_bytes:
+            acc = 0
+            for pos in range(len(items) - 1, 0, -1):
+                if acc > 0 and acc + sizes[pos] > tail_bucket_bytes:
+                    break
+                acc += sizes[pos]
+                tail_start = pos
+        for pos, (idx, name, shape) in enumerate(items):
             n = 1
             for d in shape:
                 n *= int(d)
             cap = first_bucket_bytes if not buckets else bucket_cap_bytes
             used_bytes = (cursor - cur.start) * esize
-            if cur.segments and used_bytes + n * esize > cap:
+            if cur.segments and (used_bytes + n * esize > cap or pos == tail_start):
                 cursor = _round_up(cursor, bkt_align)
                 cur.end = cursor
                 buckets.append(cur)
@@ -136,7 +155,7 @@ class GradArena:
     """
 
     def __init__(self, named_params: Iterable, first_bucket_bytes: int, bucket_cap_bytes: int,
-                 flatten_params: bool = False, grad_dtype=None):
+                 flatten_params: bool = False, grad_dtype=None, tail_bucket_bytes: int = 0):
         named = [(n, p) for n, p in named_params if p.requires_grad]
         if not named:
             raise ValueError("no trainable parameters")
@@ -151,7 +170,8 @@ class GradArena:
         self.named = named
         gdt = (lambda p: grad_dtype or p.dtype)
         self.plans = plan_arenas([(n, p.shape, gdt(p)) for n, p in named],
-                                 first_bucket_bytes, bucket_cap_bytes)
+                                 first_bucket_bytes, bucket_cap_bytes,
+                                 tail_bucket_bytes=tail_bucket_bytes)
         self.grads = {dt: torch.zeros(pl.numel, dtype=dt, device=self.device)
                       for dt, pl in self.plans.items()}
         self.params = {}

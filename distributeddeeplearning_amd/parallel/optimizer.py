@@ -98,7 +98,8 @@ class _DistributedMixin:
         if arena is None:
             arena = getattr(self, "arena", None)  # fused optimizers bring their own arena
         if arena is None:
-            arena = GradArena(named, cfg.first_bucket_bytes, cfg.fusion_threshold)
+            arena = GradArena(named, cfg.first_bucket_bytes, cfg.fusion_threshold,
+                              tail_bucket_bytes=cfg.tail_bucket_bytes)
         self._ddl_arena = arena
         self._ddl_buckets = [_BucketState(dt, b, arena.bucket_tensor(dt, b), self._ddl_passes)
                              for dt, b in arena.all_buckets()]

@@ -159,6 +159,9 @@ class EngineConfig:
     # ResNet-50; the un-overlappable tail is the last 11.5 MB) beats 8 MB (7 + 1, 6 MB tail)
     fusion_threshold: int = 32 * 1024 * 1024
     first_bucket_bytes: int = 8 * 1024 * 1024  # small first bucket: comm starts early in backward
+    # the last bucket (first layers, ready only when backward ends) holds at most this much, so the
+    # bucket before it is exchanged while the stem's backward still runs
+    tail_bucket_bytes: int = 256 * 1024
     comm_dtype: str = "auto"  # auto = gradient dtype | bf16 | fp32
     backend: str = "auto"  # auto | rccl | gloo
     engine: str = "torch"  # torch (c10d process group) | native (in-tree C++ engine)
@@ -177,6 +180,7 @@ class EngineConfig:
             fusion_threshold=env_int("HVD_FUSION_THRESHOLD", 32 * 1024 * 1024,
                                      "HOROVOD_FUSION_THRESHOLD"),
             first_bucket_bytes=env_int("HVD_FIRST_BUCKET_BYTES", 8 * 1024 * 1024),
+            tail_bucket_bytes=env_int("HVD_TAIL_BUCKET_BYTES", 256 * 1024),
             comm_dtype=env_str("HVD_COMM_DTYPE", "auto"),
             backend=env_str("HVD_BACKEND", "auto"),
             engine=env_str("HVD_ENGINE", "torch"),

@@ -168,3 +168,23 @@ def test_compression_roundtrip():
         assert back.dtype == t.dtype and torch.allclose(back, t, atol=2e-2)
     w, _ = Compression.fp16.compress(t)
     assert w.dtype == torch.float16
+
+
+def test_tail_bucket_keeps_the_last_exchange_small():
+    """The first layers' gradients arrive last; with ``tail_bucket_bytes`` they get a small bucket
+    of their own so that the large bucket before it does not wait for the end of backward."""
+    from distributeddeeplearning_amd.parallel.bucket import plan_arenas
+
+    m = resnet50()
+    ents = [(n, tuple(p.shape), torch.float32) for n, p in m.named_parameters() if p.dim() > 1]
+    base = plan_arenas(ents, 8 << 20, 32 << 20)[torch.float32]
+    tail = plan_arenas(ents, 8 << 20, 32 << 20, tail_bucket_bytes=256 << 10)[torch.float32]
+    assert len(tail.buckets) == len(base.buckets) + 1
+    last = tail.buckets[-1]
+    assert last.segments[-1].name == "conv1.weight"
+    assert (last.end - last.start) * 4 <= (256 << 10) + 4096
+    assert [s.name for b in tail.buckets for s in b.segments] == [s.name for b in base.buckets for s in b.segments]
+    # every segment still inside its bucket, buckets contiguous and aligned
+    for b in tail.buckets:
+        assert all(b.start <= s.offset and s.offset + s.numel <= b.end for s in b.segments)
+    assert all(a.end == b.start for a, b in zip(tail.buckets, tail.buckets[1:]))
