@@ -533,18 +533,31 @@ void ddl_eng_timeline_mark(const char* name, const char* cat, int phase) {
 // Returns the number of buckets; *arena_numel gets the padded arena length.
 // ---------------------------------------------------------------------------------------------
 int ddl_bucket_plan(const long long* numel, int n, int elem_size, long long first_bucket_bytes,
-                    long long bucket_cap_bytes, int seg_align_bytes, int bucket_align_bytes,
+                    long long bucket_cap_bytes, long long tail_bucket_bytes, int seg_align_bytes, int bucket_align_bytes,
                     long long* offsets, int* bucket, long long* bucket_end, long long* arena_numel) {
     if (n <= 0 || elem_size <= 0) return 0;
     const long long seg_align = std::max<long long>(seg_align_bytes / elem_size, 1);
     const long long bkt_align = std::max<long long>(bucket_align_bytes / elem_size, 1);
     auto round_up = [](long long x, long long m) { return (x + m - 1) / m * m; };
+    // small tail bucket: the last tensors (first layers) only become ready when backward ends
+    int tail_start = -1;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) total += numel[i] * elem_size;
+    if (tail_bucket_bytes > 0 && total > 4 * tail_bucket_bytes) {
+        long long acc = 0;
+        for (int i = n - 1; i >= 1; --i) {
+            const long long sz = numel[i] * elem_size;
+            if (acc > 0 && acc + sz > tail_bucket_bytes) break;
+            acc += sz;
+            tail_start = i;
+        }
+    }
     long long cursor = 0, start = 0;
     int nb = 0, in_cur = 0;
     for (int i = 0; i < n; ++i) {
         const long long cap = nb == 0 ? first_bucket_bytes : bucket_cap_bytes;
         const long long used = (cursor - start) * elem_size;
-        if (in_cur > 0 && used + numel[i] * elem_size > cap) {
+        if (in_cur > 0 && (used + numel[i] * elem_size > cap || i == tail_start)) {
             cursor = round_up(cursor, bkt_align);
             bucket_end[nb] = cursor;
             ++nb;

@@ -19,12 +19,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_native_bucket_plan_matches_python_planner():
+@pytest.mark.parametrize("tail", [0, 256 << 10])
+def test_native_bucket_plan_matches_python_planner(tail):
     from distributeddeeplearning_amd.models import resnet50
 
     m = resnet50()
     entries = [(n, p.shape, torch.float32) for n, p in m.named_parameters()]
-    plan = plan_arenas(entries, 8 << 20, 32 << 20)[torch.float32]
+    plan = plan_arenas(entries, 8 << 20, 32 << 20, tail_bucket_bytes=tail)[torch.float32]
     numel = [s.numel for s in plan.segments]  # planning (reverse) order
     n = len(numel)
     arr = (ctypes.c_longlong * n)(*numel)
@@ -33,8 +34,8 @@ def test_native_bucket_plan_matches_python_planner():
     bucket_end = (ctypes.c_longlong * n)()
     arena = ctypes.c_longlong(0)
     nb = lib.ddl_bucket_plan(arr, n, 4, ctypes.c_longlong(8 << 20), ctypes.c_longlong(32 << 20),
-                             SEG_ALIGN_BYTES, BUCKET_ALIGN_BYTES, offsets, bucket, bucket_end,
-                             ctypes.byref(arena))
+                             ctypes.c_longlong(tail), SEG_ALIGN_BYTES, BUCKET_ALIGN_BYTES, offsets,
+                             bucket, bucket_end, ctypes.byref(arena))
     assert nb == len(plan.buckets) and arena.value == plan.numel
     assert list(offsets) == [s.offset for s in plan.segments]
     assert [bucket_end[i] for i in range(nb)] == [b.end for b in plan.buckets]
