@@ -130,6 +130,28 @@ def build_probes(force=False, verbose=True):
     return outs
 
 
+def build_engine_stress(tsan=True, force=False, verbose=True):
+    """Native stress driver of the engine's TCP data plane (csrc/engine/tests/engine_stress.cpp),
+    by default under ThreadSanitizer.  Uses the ROCm LLVM clang++: g++ 11's libtsan does not
+    intercept pthread_cond_clockwait (std::condition_variable::wait_for) and reports phantom
+    double locks.  Host code only: no HIP/RCCL objects are linked."""
+    srcs = [os.path.join(ROOT, "csrc", "engine", f) for f in ("engine.cpp", "store.cpp", "tests/engine_stress.cpp")]
+    hdrs = sorted(glob.glob(os.path.join(ROOT, "csrc", "engine", "*.h")))
+    out = os.path.join(BUILD, "engine_tsan" if tsan else "engine_plain", "engine_stress")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    clang = os.path.join(rocm, "lib", "llvm", "bin", "clang++")
+    cxx = clang if os.path.exists(clang) else (shutil.which("clang++") or shutil.which("g++"))
+    if tsan and "clang" not in os.path.basename(cxx):
+        raise RuntimeError("a clang++ with the ThreadSanitizer runtime is needed for --tsan")
+    if force or _newer(out, srcs + hdrs):
+        _run([cxx, "-O1", "-g", "-std=c++17", "-pthread", "-Wall"] + (["-fsanitize=thread"] if tsan else []) +
+             ["-I", os.path.join(ROOT, "csrc", "engine")] + srcs + ["-o", out])
+        if verbose:
+            print("[build] built", os.path.relpath(out, ROOT), flush=True)
+    return out
+
+
 def build_all(force=False, jobs=8, verbose=True):
     libs = build_kernels(force, jobs, verbose), build_engine(force, jobs, verbose)
     build_probes(force, verbose)
@@ -140,5 +162,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--tsan", action="store_true", help="also build the engine stress driver under ThreadSanitizer")
     a = ap.parse_args()
+    if a.tsan:
+        print(build_engine_stress(True, a.force))
     print(build_all(a.force, a.jobs))

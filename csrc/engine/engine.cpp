@@ -20,6 +20,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -248,7 +249,7 @@ public:
         fflush(tl_);
     }
 
-    int stall_warnings = 0;
+    std::atomic<int> stall_warnings{0};
 
 private:
     StoreServer* server_ = nullptr;
@@ -260,10 +261,11 @@ private:
     std::deque<Op> queue_;
     std::map<int64_t, int> status_;
     int64_t next_handle_ = 1;
-    bool running_ = false;
+    std::atomic<bool> running_{false};  // written under mu_, read lock-free inside socket loops
     std::string last_error_;
     std::atomic<double> current_start_{0.0};
-    std::string current_name_;
+    std::string current_name_;  // guarded by cur_mu_ (worker writes, watchdog reads)
+    std::mutex cur_mu_;
     std::mutex tl_mu_;
     FILE* tl_ = nullptr;
     bool tl_first_ = true;
@@ -281,18 +283,25 @@ private:
     void watch() {
         bool warned = false;
         double warned_for = 0.0;
+        // wake at least twice per warning interval (200 ms at most, 1 ms at least)
+        const int period_ms = (int)std::min(200.0, std::max(1.0, stall_warning_s * 500.0));
         while (true) {
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                if (cv_.wait_for(lk, std::chrono::milliseconds(200), [&] { return !running_; })) return;
+                if (cv_.wait_for(lk, std::chrono::milliseconds(period_ms), [&] { return !running_; })) return;
             }
             const double st = current_start_.load();
             if (st <= 0.0) { warned = false; continue; }
             const double el = (now_us() - st) * 1e-6;
             if (el > stall_warning_s && !(warned && warned_for == st)) {
-                fprintf(stderr, "[ddl engine rank %d] WARNING: collective '%s' has been waiting for %.0f s "
+                std::string name;
+                {
+                    std::lock_guard<std::mutex> g(cur_mu_);
+                    name = current_name_;
+                }
+                fprintf(stderr, "[ddl engine rank %d] WARNING: collective '%s' has been waiting for %.1f s "
                                 "(a peer may have stalled or submitted collectives in a different order)\n",
-                        rank, current_name_.c_str(), el);
+                        rank, name.c_str(), el);
                 warned = true; warned_for = st;
                 ++stall_warnings;
             }
@@ -404,7 +413,10 @@ private:
                 queue_.pop_front();
                 status_[op.handle] = RUNNING;
             }
-            current_name_ = op.name;
+            {
+                std::lock_guard<std::mutex> g(cur_mu_);
+                current_name_ = op.name;
+            }
             const double t0 = now_us();
             current_start_.store(t0);
             timeline_event(op.name, op.kind == ALLREDUCE ? "ALLREDUCE" : op.kind == BROADCAST ? "BROADCAST"
@@ -473,7 +485,7 @@ void ddl_eng_shutdown() {
 const char* ddl_eng_last_error() { return g_err.c_str(); }
 int ddl_eng_rank() { return g_engine ? g_engine->rank : -1; }
 int ddl_eng_size() { return g_engine ? g_engine->size : -1; }
-int ddl_eng_stall_warnings() { return g_engine ? g_engine->stall_warnings : 0; }
+int ddl_eng_stall_warnings() { return g_engine ? g_engine->stall_warnings.load() : 0; }
 
 long long ddl_eng_allreduce_async(void* buf, long long count, int dtype, int redop, const char* name) {
     if (!g_engine) return -1;
