@@ -130,9 +130,12 @@ def main(argv=None):
         value = global_batch * args.steps / elapsed
         base = _read_baseline()
         # the stock number is a 1-GPU figure; compare per-GPU throughput against it
-        vs = (value / world) / base if base else None
+        # (measured for ResNet-50, batch 256, bf16 only: other configurations report null)
+        flagship = args.model == "resnet50" and args.batch == 256 and args.image == 224 and dtype == torch.bfloat16
+        vs = (value / world) / base if (base and flagship) else None
+        pretty = {"resnet%d" % d: "ResNet-%d" % d for d in (18, 34, 50, 101, 152, 200)}.get(args.model, args.model)
         print(json.dumps({
-            "metric": "images/sec (whole node) ResNet-50 synthetic 224x224 training",
+            "metric": "images/sec (whole node) %s synthetic %dx%d training" % (pretty, args.image, args.image),
             "value": round(value, 2),
             "unit": "images/sec",
             "n_gpus": world,
@@ -143,6 +146,8 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None if vs is None else round(vs, 4),
+            "baseline": "stock PyTorch-ROCm ResNet-50 bf16 channels_last batch 256 on one MI355X "
+                        "(BASELINE_MEASURED.json); ratio of per-GPU throughput",
             "dtype": "bf16" if dtype == torch.bfloat16 else "fp32",
             "data": "synthetic (on-GPU Philox pool, random-init weights)",
             "final_loss": round(final_loss, 4),
