@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--aten", action="store_true")
+    ap.add_argument("--blaslt", action="store_true",
+                    help="1x1 stride-1 shapes: also time the plain library GEMM (torch.matmul -> hipBLASLt)")
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
@@ -129,6 +131,19 @@ def main():
             tot["aten_fwd"] += ta * count
             tot["aten_bwd"] += tb * count
             line += " | aten fwd %8.1f bwd %8.1f" % (ta * 1e3, tb * 1e3)
+        if args.blaslt and k == 1 and stride == 1:
+            x2 = x.permute(0, 2, 3, 1).reshape(M, cin)
+            w2 = w.reshape(cout, cin)
+            o2 = torch.empty((M, cout), dtype=bf, device=dev)
+
+            def lt():
+                torch.matmul(x2, w2.t(), out=o2)
+
+            tl = timeit(lt, args.iters)
+            row["blaslt_us"] = tl * 1e3
+            tot["blaslt"] = tot.get("blaslt", 0.0) + tl * count
+            tot["fwd_1x1s1"] = tot.get("fwd_1x1s1", 0.0) + tf_ * count
+            line += " | hipBLASLt gemm %7.1f us %5.0f TF/s" % (tl * 1e3, flops / tl / 1e9)
         print(line, flush=True)
         rows.append(row)
         del x, w, y, dy, dx, stats

@@ -37,6 +37,7 @@ struct IGemmParams {
     int Hout, Wout, N, M;
     int R, S, ostride, pad, pad_w, idil_log2;
     int tiles_m, tiles_n;
+    int stat_rows;         // rows of `stats`: one per 128 output rows (a 256-row tile writes two)
     int addend_sub2;  // addend is [B][Hout/2][Wout/2][N]: added at even (h, w) pixels only
     int parity, tiles_per_class, Mc;  // stride-2 backward-data: M ordered by output-pixel parity class
     // fused backward epilogues (EPI 2 / 3), all tensors [M][N] like y:
@@ -60,6 +61,7 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 //      4 = 3 plus the sum g / sum g*y partials of the BatchNorm that feeds that ReLU (ep_y).
 template <int BM, int BN, int BK, int EPI, bool ADDEND>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p) {
+    static_assert(BM % 128 == 0, "statistics rows are per 128 output rows");
     constexpr bool STATS = EPI == 1 || EPI == 2 || EPI == 4;
     constexpr int CPR = BK / 8;            // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;         // rows covered per pass of the 256 threads
@@ -88,12 +90,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     const int n0 = tile_n * BN;
     // Parity mode (backward-data of a stride-2 conv): the input gradient is dy dilated by 2, so
     // an output pixel (hi, wi) only sees taps with r = (pad + hi) mod 2, s = (pad_w + wi) mod 2.
-    // Rows are ordered by parity class (hi & 1, wi & 1): a tile has ONE class, walks only its
+    // Rows are grouped by parity class (hi & 1, wi & 1): a tile has ONE class, walks only its
     // live taps (9 instead of 36 tap visits over the four classes of a 3x3) and skips the rest.
     int m0 = tile_m * BM, pcls = 0, ph = 0, pw = 0, m_lim = p.M;
     if (p.parity) {
-        pcls = tile_m / p.tiles_per_class;
-        m0 = (tile_m - pcls * p.tiles_per_class) * BM;
+        // classes interleaved over the tile index: a 3x3 tile visits 1, 2, 2 or 4 taps depending on
+        // its class, and class-major order handed the XCDs that got the last class 4x the work of
+        // the first (stride-2 backward-data ran at 0.65x the forward rate)
+        pcls = tile_m & 3;
+        m0 = (tile_m >> 2) * BM;
         ph = pcls >> 1; pw = pcls & 1;
         m_lim = p.Mc;
     }
@@ -248,6 +253,35 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     // kernel against 4.5 TB/s for a plain streaming kernel — profiles/r1_notes.md.)
     constexpr int BATCH = OITER < 4 ? OITER : 4;
     const bool col_ok = n < p.N;
+    constexpr int SUB = BM / 128, SUB_ITERS = OITER / SUB;  // a thread's rows of one 128-row sub-tile are consecutive iterations
+    static_assert(SUB_ITERS % BATCH == 0, "a batch never straddles two sub-tiles");
+    auto emit_stats = [&](int sub) {
+        // lanes with equal (tid % OCPR) hold the same channels: fold the wave, then the 4 waves
+        float* red = reinterpret_cast<float*>(smem + BM * OSTR);  // [4 waves][2][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = OCPR; o < 64; o <<= 1) {
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+        }
+        if (sub > 0) __syncthreads();  // the previous sub-tile's fold has been read
+        float* r1 = red + wid * 2 * BN;
+        if (lane < OCPR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { r1[lane * 8 + e] = s1[e]; r1[BN + lane * 8 + e] = s2[e]; }
+        }
+        __syncthreads();
+        const int srow = tile_m * SUB + sub;
+        if (tid < 2 * BN && srow < p.stat_rows) {
+            float t = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
+            int which = tid / BN, c = tid - which * BN;
+            if (n0 + c < p.N) p.stats[((long long)srow * 2 + which) * p.N + n0 + c] = t;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    };
 #pragma unroll
     for (int it0 = 0; it0 < OITER; it0 += BATCH) {
         long long off[BATCH], aoff[BATCH];
@@ -323,29 +357,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
             }
             if (ok[b]) *reinterpret_cast<bf16x8*>(p.y + off[b]) = v;
         }
-    }
-    if (STATS) {
-        // lanes with equal (tid % OCPR) hold the same channels: fold the wave, then the 4 waves
-        float* red = reinterpret_cast<float*>(smem + BM * OSTR);  // [4 waves][2][BN]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = OCPR; o < 64; o <<= 1) {
-                s1[e] += __shfl_xor(s1[e], o, 64);
-                s2[e] += __shfl_xor(s2[e], o, 64);
-            }
-        }
-        float* r1 = red + wid * 2 * BN;
-        if (lane < OCPR) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { r1[lane * 8 + e] = s1[e]; r1[BN + lane * 8 + e] = s2[e]; }
-        }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            float t = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
-            int which = tid / BN, c = tid - which * BN;
-            if (n0 + c < p.N) p.stats[((long long)tile_m * 2 + which) * p.N + n0 + c] = t;
-        }
+        if (STATS && (it0 + BATCH) % SUB_ITERS == 0) emit_stats((it0 + BATCH) / SUB_ITERS - 1);
     }
 }
 
@@ -422,12 +434,14 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
     if (addend_sub2 && (!addend || (Hout & 1) || (Wout & 1))) return DDL_EINVAL;
     p.addend_sub2 = addend_sub2;
     p.tiles_m = (int)((M + 127) / 128);
+    p.stat_rows = p.tiles_m;
     p.parity = 0; p.tiles_per_class = 0; p.Mc = 0;
     if (igemm_parity(idil, ostride, Hout, Wout) && (!stats || ep_y)) {
         p.parity = 1;
         p.Mc = (int)(M / 4);
         p.tiles_per_class = (p.Mc + 127) / 128;
         p.tiles_m = 4 * p.tiles_per_class;
+        p.stat_rows = p.tiles_m;
     }
     static const int force_bk = getenv("DDL_CONV_BK") ? atoi(getenv("DDL_CONV_BK")) : 0;  // tuning knob
     // K-tile depth per shape class, from benchmarks/kernel_bench.py on MI355X (profiles/): the
@@ -439,6 +453,18 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
         return bk64 ? launch_cfg<128, 64, 64>(p, stream) : launch_cfg<128, 64, 32>(p, stream);
     }
     p.tiles_n = (N + 127) / 128;
+    // 256x128 block tile (wave tile 128x64: a quarter fewer LDS and L2->LDS bytes per FLOP) where the
+    // reduction is long, two or more N tiles share the A panel and enough tiles remain to fill the
+    // chip: c4 3x3 256->256 @14 fwd 88 -> 74 us, dgrad 85 -> 70 us (805-840 TFLOP/s); c3 1x1
+    // 1024->256 fwd 45 -> 39 us; loses on short reductions and where < 1.5 tiles per CU are left
+    // (profiles/r1_notes.md).  DDL_CONV_BM=128|256 forces one or the other.
+    static const int force_bm = getenv("DDL_CONV_BM") ? atoi(getenv("DDL_CONV_BM")) : 0;  // tuning knob
+    const long long tiles256 = ((M + 255) / 256) * p.tiles_n;
+    const bool big = force_bm == 256 || (force_bm != 128 && !bk64 && N >= 256 && (long long)R * S * C >= 1024 && tiles256 >= 384);
+    if (big && !p.parity) {
+        p.tiles_m = (int)((M + 255) / 256);
+        return bk64 ? launch_cfg<256, 128, 64>(p, stream) : launch_cfg<256, 128, 32>(p, stream);
+    }
     return bk64 ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
 }
 

@@ -1,6 +1,7 @@
 #!/bin/bash
-for t in 134217728 33554432 16777216 8388608 4194304; do
-  echo "== HVD_FUSION_THRESHOLD=$t"
-  HVD_FORCE_COLLECTIVES=1 HVD_FUSION_THRESHOLD=$t HVD_FIRST_BUCKET_BYTES=$t timeout -k 10 200 python -u bench.py 2>&1 | tail -1 | grep -o "ms_per_step\": [0-9.]*" | tr '\n' ' ' || exit 1
-  echo
+set -o pipefail
+timeout -k 10 300 python -u -m pytest tests/test_gpu_kernels.py -x -q --timeout 120 --timeout-method thread 2>&1 | tail -2 || exit 1
+timeout -k 10 200 python -u benchmarks/kernel_bench.py --iters 20 --only b2,c2,d2 2>&1 | grep -v amdgpu.ids | cut -c1-120 || exit 1
+for i in 1 2; do
+  timeout -k 10 200 python -u bench.py 2>&1 | tail -1 | grep -o "ms_per_step\": [0-9.]*" || exit 1
 done
