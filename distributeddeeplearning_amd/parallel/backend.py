@@ -43,6 +43,7 @@ class _State:
         self.comm = None
         self.engine = "torch"
         self.owns_default_group = False
+        self.cpu_affinity = None  # CPU set chosen by utils.affinity (None = left alone)
         self.config = EngineConfig()
         self.lock = threading.Lock()
 
@@ -94,6 +95,10 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
         if want == "rccl":
             # Pin the device before the communicator exists: RCCL binds to the current device.
             torch.cuda.set_device(_S.local_rank % n_dev)
+            if world > 1:  # host threads next to the GPU they feed (best effort, HVD_NUMA_BIND=0 disables)
+                from ..utils.affinity import bind_to_gpu_numa
+
+                _S.cpu_affinity = bind_to_gpu_numa(_S.local_rank % n_dev)
 
         engine = (cfg.engine or "torch").lower()
         if engine not in ("torch", "native"):

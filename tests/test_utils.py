@@ -171,3 +171,40 @@ def test_metrics_writer(tmp_path):
     w2 = MetricsWriter(str(tmp_path / "n.jsonl"), rank=1)
     w2.write(step=1)
     assert not (tmp_path / "n.jsonl").exists()
+
+
+def test_numa_affinity_helpers(tmp_path, monkeypatch):
+    """utils/affinity.py: cpulist parsing, sysfs lookups against a fake tree, and the binding
+    rules (never widen, never below min_cpus, HVD_NUMA_BIND=0 leaves the mask alone)."""
+    import os
+    from distributeddeeplearning_amd.utils import affinity as A
+
+    assert A.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert A.parse_cpulist("") == set()
+    bdf = "0000:75:00.0"
+    dev = tmp_path / "bus" / "pci" / "devices" / bdf
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    allowed = sorted(os.sched_getaffinity(0))
+    (node / "cpulist").write_text(",".join(str(c) for c in allowed[: max(2, len(allowed) // 2)]))
+    assert A.gpu_numa_node(bdf, str(tmp_path)) == 1
+    assert A.gpu_numa_node("0000:00:00.0", str(tmp_path)) is None
+    assert A.numa_cpus(1, str(tmp_path)) == set(allowed[: max(2, len(allowed) // 2)])
+    assert A.numa_cpus(7, str(tmp_path)) == set()
+
+    calls = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: calls.append(set(cpus)))
+    monkeypatch.setenv("HVD_NUMA_BIND", "0")
+    assert A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf) is None and not calls
+    monkeypatch.setenv("HVD_NUMA_BIND", "1")
+    got = A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf)
+    if len(allowed) >= 4:
+        assert got == set(allowed[: len(allowed) // 2]) and calls == [got]
+    # unknown node (-1) and a node with no allowed CPU leave the mask alone
+    (dev / "numa_node").write_text("-1\n")
+    assert A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf) is None
+    (dev / "numa_node").write_text("1\n")
+    (node / "cpulist").write_text("100000-100003")
+    assert A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf) is None
