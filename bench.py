@@ -61,6 +61,9 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--device", default=None, help="cuda|cpu (default: cuda when available)")
     ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one HIP graph after the first warm-up steps "
+                         "(training/graph.py); needs --warmup >= 2")
     return ap.parse_args(argv)
 
 
@@ -95,8 +98,18 @@ def main(argv=None):
                                    height=args.image, width=args.image, device=device,
                                    dtype=dtype, rank=rank, world=world)
 
+    graphed = None
+    if args.graph and use_cuda and args.warmup >= 2:
+        from distributeddeeplearning_amd.training.graph import GraphedTrainStep
+
+        graphed = GraphedTrainStep(model, opt, ops.softmax_cross_entropy,
+                                   warmup=min(3, args.warmup - 1),
+                                   allow_collectives=os.environ.get("DDL_GRAPH_COLLECTIVES", "0") == "1")
+
     def one_step():
         images, labels = loader.batch()
+        if graphed is not None:
+            return graphed(images, labels)
         opt.zero_grad()
         loss = ops.softmax_cross_entropy(model(images), labels)
         loss.backward()
@@ -152,6 +165,7 @@ def main(argv=None):
             "data": "synthetic (on-GPU Philox pool, random-init weights)",
             "final_loss": round(final_loss, 4),
             "ops_backend": "hip" if (use_cuda and ops.backend() != "aten") else "aten",
+            "hip_graph": bool(graphed is not None and graphed.graphed),
             "config": {"model": args.model, "global_batch": global_batch,
                        "per_gpu_batch": args.batch, "image": args.image,
                        "optimizer": args.optimizer, "parallelism": "dp%d" % world},

@@ -98,7 +98,11 @@ extern "C" int ddl_philox_labels(void* out, long long n, int n_classes, uint64_t
 template <bool GRAD_BF16, bool HAS_LOWP>
 __global__ void __launch_bounds__(256) fused_sgd_kernel(float* __restrict__ w, const void* __restrict__ gv,
                                                        float* __restrict__ v, bf16_t* __restrict__ lowp,
-                                                       long long n, float lr, float mu, float wd, int nesterov) {
+                                                       long long n, float lr, float mu, float wd, int nesterov,
+                                                       const float* __restrict__ lr_scale) {
+    // optional device-side multiplier: a captured HIP graph keeps `lr` by value, the schedule
+    // then moves the learning rate by rewriting one float on the device
+    if (lr_scale) lr *= *lr_scale;
     long long n8 = n >> 3;
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
@@ -141,17 +145,22 @@ __global__ void __launch_bounds__(256) fused_sgd_kernel(float* __restrict__ w, c
     }
 }
 
-extern "C" int ddl_fused_sgd(void* w, const void* g, void* v, void* lowp, long long n, int grad_is_bf16,
-                             float lr, float mu, float wd, int nesterov, hipStream_t stream) {
+extern "C" int ddl_fused_sgd_ex(void* w, const void* g, void* v, void* lowp, long long n, int grad_is_bf16,
+                                float lr, float mu, float wd, int nesterov, const void* lr_scale, hipStream_t stream) {
     if (!w || !g || !v || n < 0) return DDL_EINVAL;
     if (n == 0) return DDL_OK;
     if (!ddl_aligned16(w) || !ddl_aligned16(g) || !ddl_aligned16(v) || (lowp && !ddl_aligned16(lowp))) return DDL_EALIGN;
     dim3 grid(ddl_stream_grid((n + 7) / 8, 256)), block(256);
-#define LAUNCH(GB, LP) hipLaunchKernelGGL((fused_sgd_kernel<GB, LP>), grid, block, 0, stream, (float*)w, g, (float*)v, (bf16_t*)lowp, n, lr, mu, wd, nesterov)
+#define LAUNCH(GB, LP) hipLaunchKernelGGL((fused_sgd_kernel<GB, LP>), grid, block, 0, stream, (float*)w, g, (float*)v, (bf16_t*)lowp, n, lr, mu, wd, nesterov, (const float*)lr_scale)
     if (grad_is_bf16) { if (lowp) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (lowp) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
     return ddl_launch_status();
+}
+
+extern "C" int ddl_fused_sgd(void* w, const void* g, void* v, void* lowp, long long n, int grad_is_bf16,
+                             float lr, float mu, float wd, int nesterov, hipStream_t stream) {
+    return ddl_fused_sgd_ex(w, g, v, lowp, n, grad_is_bf16, lr, mu, wd, nesterov, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -207,7 +216,9 @@ __global__ void __launch_bounds__(256) fused_lars_kernel(float* __restrict__ w, 
                                                         bf16_t* __restrict__ lowp, const float* __restrict__ ratio,
                                                         const long long* __restrict__ seg_start,
                                                         const long long* __restrict__ seg_end, int nseg, long long n,
-                                                        float lr, float mu, float wd) {
+                                                        float lr, float mu, float wd,
+                                                        const float* __restrict__ lr_scale) {
+    if (lr_scale) lr *= *lr_scale;
     long long c0 = (long long)blockIdx.x * LARS_CHUNK;
     long long c1 = c0 + LARS_CHUNK < n ? c0 + LARS_CHUNK : n;
     int k = find_segment(seg_start, nseg, c0);
@@ -240,16 +251,22 @@ extern "C" int ddl_segmented_sqnorms(const void* w, const void* g, int grad_is_b
     return ddl_launch_status();
 }
 
-extern "C" int ddl_fused_lars(void* w, const void* g, void* v, void* lowp, const void* ratio, const void* seg_start,
-                              const void* seg_end, int nseg, long long n, int grad_is_bf16, float lr, float mu,
-                              float wd, hipStream_t stream) {
+extern "C" int ddl_fused_lars_ex(void* w, const void* g, void* v, void* lowp, const void* ratio, const void* seg_start,
+                                 const void* seg_end, int nseg, long long n, int grad_is_bf16, float lr, float mu,
+                                 float wd, const void* lr_scale, hipStream_t stream) {
     if (!w || !g || !v || !ratio || !seg_start || !seg_end || nseg <= 0 || n <= 0) return DDL_EINVAL;
     dim3 grid((unsigned)((n + LARS_CHUNK - 1) / LARS_CHUNK)), block(256);
-#define LAUNCH(GB, LP) hipLaunchKernelGGL((fused_lars_kernel<GB, LP>), grid, block, 0, stream, (float*)w, g, (float*)v, (bf16_t*)lowp, (const float*)ratio, (const long long*)seg_start, (const long long*)seg_end, nseg, n, lr, mu, wd)
+#define LAUNCH(GB, LP) hipLaunchKernelGGL((fused_lars_kernel<GB, LP>), grid, block, 0, stream, (float*)w, g, (float*)v, (bf16_t*)lowp, (const float*)ratio, (const long long*)seg_start, (const long long*)seg_end, nseg, n, lr, mu, wd, (const float*)lr_scale)
     if (grad_is_bf16) { if (lowp) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (lowp) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
     return ddl_launch_status();
+}
+
+extern "C" int ddl_fused_lars(void* w, const void* g, void* v, void* lowp, const void* ratio, const void* seg_start,
+                              const void* seg_end, int nseg, long long n, int grad_is_bf16, float lr, float mu,
+                              float wd, hipStream_t stream) {
+    return ddl_fused_lars_ex(w, g, v, lowp, ratio, seg_start, seg_end, nseg, n, grad_is_bf16, lr, mu, wd, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -133,15 +133,19 @@ def _f32(v):
     return ctypes.c_float(float(v))
 
 
-def fused_sgd_(w, g, v, lowp, lr, mu, wd, nesterov) -> None:
-    """K14: one launch updates fp32 weights/momentum (+ bf16 shadow) over a flat range."""
+def fused_sgd_(w, g, v, lowp, lr, mu, wd, nesterov, lr_scale=None) -> None:
+    """K14: one launch updates fp32 weights/momentum (+ bf16 shadow) over a flat range.
+    ``lr_scale``: optional 1-element fp32 device tensor multiplied into ``lr`` on the device
+    (learning-rate schedules under a captured HIP graph)."""
     n = w.numel()
     assert w.dtype == torch.float32 and v.dtype == torch.float32 and v.numel() == n
     assert g.numel() == n and g.dtype in (torch.float32, torch.bfloat16)
     assert lowp is None or (lowp.dtype == torch.bfloat16 and lowp.numel() == n)
-    check(lib().ddl_fused_sgd(ptr(w), ptr(g), ptr(v), ptr(lowp), _i64(n),
-                              ctypes.c_int(int(g.dtype == torch.bfloat16)), _f32(lr), _f32(mu),
-                              _f32(wd), ctypes.c_int(int(bool(nesterov))), stream()), "fused_sgd")
+    assert lr_scale is None or (lr_scale.dtype == torch.float32 and lr_scale.numel() == 1)
+    check(lib().ddl_fused_sgd_ex(ptr(w), ptr(g), ptr(v), ptr(lowp), _i64(n),
+                                 ctypes.c_int(int(g.dtype == torch.bfloat16)), _f32(lr), _f32(mu),
+                                 _f32(wd), ctypes.c_int(int(bool(nesterov))), ptr(lr_scale),
+                                 stream()), "fused_sgd")
 
 
 def segmented_norms(w, g, seg_offsets, seg_ends):
@@ -155,14 +159,15 @@ def segmented_norms(w, g, seg_offsets, seg_ends):
     return out[0], out[1]
 
 
-def fused_lars_(w, g, v, lowp, ratios, seg_offsets, seg_ends, lr, mu, wd) -> None:
+def fused_lars_(w, g, v, lowp, ratios, seg_offsets, seg_ends, lr, mu, wd, lr_scale=None) -> None:
     """K15 pass 2: v = mu*v + lr*ratio[k]*(g + wd*w); w -= v."""
     nseg = seg_ends.numel()
     assert ratios.dtype == torch.float32 and ratios.numel() == nseg and ratios.is_contiguous()
-    check(lib().ddl_fused_lars(ptr(w), ptr(g), ptr(v), ptr(lowp), ptr(ratios), ptr(seg_offsets),
-                               ptr(seg_ends), ctypes.c_int(nseg), _i64(w.numel()),
-                               ctypes.c_int(int(g.dtype == torch.bfloat16)), _f32(lr), _f32(mu),
-                               _f32(wd), stream()), "fused_lars")
+    assert lr_scale is None or (lr_scale.dtype == torch.float32 and lr_scale.numel() == 1)
+    check(lib().ddl_fused_lars_ex(ptr(w), ptr(g), ptr(v), ptr(lowp), ptr(ratios), ptr(seg_offsets),
+                                  ptr(seg_ends), ctypes.c_int(nseg), _i64(w.numel()),
+                                  ctypes.c_int(int(g.dtype == torch.bfloat16)), _f32(lr), _f32(mu),
+                                  _f32(wd), ptr(lr_scale), stream()), "fused_lars")
 
 
 def nchw_to_nhwc_normalize(x, mean=None, sd=None, in_scale=1.0):

@@ -77,6 +77,9 @@ class _ArenaOptimizer(Optimizer):
                            "adapt": adapt, "segments": [seg]}
                     self.runs.append(cur)
         self._step = 0
+        # device-side learning-rate multiplier (see freeze_lr): None = lr is passed by value
+        self.lr_scale = None
+        self._frozen_lr = None
         try:  # gradients are arena views: fused HIP blocks may accumulate into them directly
             from ..ops import hip_ops as _hip_ops
 
@@ -95,6 +98,33 @@ class _ArenaOptimizer(Optimizer):
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_()
+
+    # -- learning rate under a captured HIP graph -------------------------------------------
+    def freeze_lr(self):
+        """From now on the kernels receive the CURRENT lr by value times a 1-element device
+        tensor (``lr_scale``).  A captured graph (training/graph.py) then follows schedules:
+        ``sync_lr()`` — outside the graph — rewrites that float when ``param_groups[0]["lr"]``
+        moved.  HIP kernels only; the CPU reference path keeps reading ``lr`` directly."""
+        if self.lr_scale is None:
+            self._frozen_lr = float(self.param_groups[0]["lr"])
+            self.lr_scale = torch.ones(1, dtype=torch.float32, device=self.arena.device)
+            self._scale_written = 1.0
+        return self.lr_scale
+
+    def sync_lr(self):
+        if self.lr_scale is None:
+            return
+        lr = float(self.param_groups[0]["lr"])
+        scale = lr / self._frozen_lr if self._frozen_lr != 0.0 else 0.0
+        if scale != self._scale_written:
+            self.lr_scale.fill_(scale)
+            self._scale_written = scale
+
+    def _kernel_lr(self, lr):
+        """(lr by value, device multiplier) for the HIP kernels."""
+        if self.lr_scale is None:
+            return lr, None
+        return self._frozen_lr, self.lr_scale
 
     @staticmethod
     def _notify_weights_changed(hip):
@@ -208,7 +238,8 @@ class FusedSGD(_ArenaOptimizer):
             v = self.momentum_buf[dt][a:b]
             if hip:
                 lowp = self.arena.params[dt][a:b] if dt in self.master else None
-                kernels.fused_sgd_(w, grads, v, lowp, lr, mu, run_wd, nesterov)
+                klr, kscale = self._kernel_lr(lr)
+                kernels.fused_sgd_(w, grads, v, lowp, klr, mu, run_wd, nesterov, kscale)
                 continue
             g = grads.to(torch.float32)
             if run_wd:
@@ -278,7 +309,8 @@ class FusedLARS(_ArenaOptimizer):
             if not run["adapt"]:
                 if hip:
                     lowp = self.arena.params[dt][a:b] if dt in self.master else None
-                    kernels.fused_sgd_(w[a:b], grads[a:b], v[a:b], lowp, lr, mu, run_wd, False)
+                    klr, kscale = self._kernel_lr(lr)
+                    kernels.fused_sgd_(w[a:b], grads[a:b], v[a:b], lowp, klr, mu, run_wd, False, kscale)
                     continue
                 g = grads[a:b].to(torch.float32)
                 if run_wd:
@@ -290,8 +322,9 @@ class FusedLARS(_ArenaOptimizer):
             ratios = self.trust_ratios(run)
             if hip:
                 lowp = self.arena.params[dt][a:b] if dt in self.master else None
+                klr, kscale = self._kernel_lr(lr)
                 kernels.fused_lars_(w[a:b], grads[a:b], v[a:b], lowp, ratios.contiguous(),
-                                    run["seg_offsets"], run["seg_ends"], lr, mu, run_wd)
+                                    run["seg_offsets"], run["seg_ends"], klr, mu, run_wd, kscale)
                 continue
             for k, s in enumerate(run["segments"]):
                 sl = slice(s.offset, s.offset + s.numel)
