@@ -198,23 +198,29 @@ __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 // K7: z = act(y*scale[c] + shift[c] [+ residual])
 // ---------------------------------------------------------------------------------------------
-template <bool RELU, bool RES, bool NT>
+// RES: 0 none, 1 residual tensor added as stored, 2 residual = rscale[c]*res + rshift[c] (the raw
+// output of the projection-shortcut conv with ITS BatchNorm applied on the fly: the shortcut's
+// normalised output is never written to or re-read from memory)
+template <bool RELU, int RES, bool NT>
 __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const bf16_t* __restrict__ res,
+                                                          const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                           bf16_t* __restrict__ z, long long nchunks, int cchunks) {
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
         int c = (int)(i % cchunks) * 8;
         bf16x8 v = ld8<NT>(y + (i << 3));
-        float sc[8], sh[8];
+        float sc[8], sh[8], rsc[8], rsh[8];
         load8f(scale + c, sc); load8f(shift + c, sh);
         bf16x8 r;
         if (RES) r = ld8<NT>(res + (i << 3));
+        if (RES == 2) { load8f(rscale + c, rsc); load8f(rshift + c, rsh); }
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float f = bn_affine(bf2f(v[e]), sc[e], sh[e]);
-            if (RES) f += bf2f(r[e]);
+            if (RES == 1) f += bf2f(r[e]);
+            if (RES == 2) f += bn_affine(bf2f(r[e]), rsc[e], rsh[e]);
             if (RELU) f = fmaxf(f, 0.f);
             o[e] = f2bf(f);
         }
@@ -783,20 +789,30 @@ extern "C" int ddl_bn_eval_coeffs(const void* gamma, const void* beta, const voi
     return ddl_launch_status();
 }
 
-extern "C" int ddl_bn_apply_fwd(const void* y, const void* scale, const void* shift, const void* res, void* z,
-                                long long M, int C, int relu, hipStream_t stream) {
+extern "C" int ddl_bn_apply_fwd_ex(const void* y, const void* scale, const void* shift, const void* res,
+                                   const void* rscale, const void* rshift, void* z,
+                                   long long M, int C, int relu, hipStream_t stream) {
     CHK(y && scale && shift && z && M > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
+    CHK((rscale == nullptr) == (rshift == nullptr) && (!rscale || res), DDL_EINVAL);
     CHK(ddl_aligned16(y) && ddl_aligned16(z) && ddl_aligned16(scale) && ddl_aligned16(shift) && (!res || ddl_aligned16(res)), DDL_EALIGN);
+    CHK(!rscale || (ddl_aligned16(rscale) && ddl_aligned16(rshift)), DDL_EALIGN);
     long long nchunks = M * (C >> 3);
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
     const bool nt = M * C * 2 >= nt_threshold_bytes();
-#define L2(R, S, N) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S, N>), grid, block, 0, stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (bf16_t*)z, nchunks, C >> 3)
+    const int rmode = !res ? 0 : (rscale ? 2 : 1);
+#define L2(R, S, N) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S, N>), grid, block, 0, stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (const float*)rscale, (const float*)rshift, (bf16_t*)z, nchunks, C >> 3)
 #define L(R, S) do { if (nt) L2(R, S, true); else L2(R, S, false); } while (0)
-    if (relu) { if (res) L(true, true); else L(true, false); }
-    else { if (res) L(false, true); else L(false, false); }
+#define LR(R) do { if (rmode == 2) L(R, 2); else if (rmode == 1) L(R, 1); else L(R, 0); } while (0)
+    if (relu) LR(true); else LR(false);
+#undef LR
 #undef L2
 #undef L
     return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_apply_fwd(const void* y, const void* scale, const void* shift, const void* res, void* z,
+                                long long M, int C, int relu, hipStream_t stream) {
+    return ddl_bn_apply_fwd_ex(y, scale, shift, res, nullptr, nullptr, z, M, C, relu, stream);
 }
 
 extern "C" int ddl_bn_bwd_blocks(long long M) {

@@ -453,8 +453,12 @@ def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True, part
 # saved [4, C] coefficient block is addressed the same way: each avoided tensor object (an
 # allocation or a view) is 3-5 us of host time, ~30 of them per layer and step, and the host has
 # to keep ahead of ~50 us kernels in the late layers (profiles/r1_notes.md).
-def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentum, eps, relu):
-    """Training-mode conv -> BatchNorm(+residual)(+ReLU).  Returns (y, z, coeffs[4, C])."""
+def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentum, eps, relu,
+              apply=True, res_coeffs=None):
+    """Training-mode conv -> BatchNorm(+residual)(+ReLU).  Returns (y, z, coeffs[4, C]).
+    ``apply=False`` stops after the statistics (z is None): the caller folds this BatchNorm into
+    a later kernel.  ``res_coeffs``: coefficient block of such a deferred BatchNorm whose raw conv
+    output is passed as ``residual``."""
     B, C, H, W = x.shape
     Kc, Cw, R, S = w.shape
     if Cw != C:
@@ -474,8 +478,15 @@ def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentu
     cb = coeffs.data_ptr()
     K.bn_fwd_finalize(st, T, Kc, M, 128, gamma, beta, rmean, rvar, momentum, eps,
                       cb, cb + 4 * Kc, cb + 8 * Kc, cb + 12 * Kc, work=wk)
+    if not apply:
+        return y, None, coeffs
     z = torch.empty_like(y)
-    K.bn_apply_fwd(y, cb + 8 * Kc, cb + 12 * Kc, residual, z, M, Kc, relu)
+    if res_coeffs is not None:
+        rb = res_coeffs.data_ptr()
+        K.bn_apply_fwd(y, cb + 8 * Kc, cb + 12 * Kc, residual, z, M, Kc, relu,
+                       rb + 8 * Kc, rb + 12 * Kc)
+    else:
+        K.bn_apply_fwd(y, cb + 8 * Kc, cb + 12 * Kc, residual, z, M, Kc, relu)
     return y, z, coeffs
 
 
@@ -787,8 +798,12 @@ class ResidualBlockFn(Function):
         if has_ds:
             wd, gd, bd, rmd, rvd = groups[units]
             if training:
-                yd, shortcut, cd = _unit_fwd(x, wd, ds_stride, 0, gd, bd, None, rmd, rvd, momentum,
-                                             eps, False)
+                # the projection's BatchNorm is applied inside the last unit's residual add: its
+                # normalised output is never materialised (one write + one read of the block's
+                # widest tensor less)
+                yd, _, cd = _unit_fwd(x, wd, ds_stride, 0, gd, bd, None, rmd, rvd, momentum,
+                                      eps, False, apply=False)
+                shortcut = yd
             else:
                 yd, st = _conv_fwd(x, wd, ds_stride, 0, training)
                 shortcut, cd = _bn_fwd(yd, gd, bd, None, st, rmd, rvd, training, momentum, eps,
@@ -799,7 +814,8 @@ class ResidualBlockFn(Function):
             last = i == units - 1
             if training:
                 y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, shortcut if last else None,
-                                    rm, rv, momentum, eps, True)
+                                    rm, rv, momentum, eps, True,
+                                    res_coeffs=cd if (last and has_ds) else None)
             else:
                 y, st = _conv_fwd(cur, w, strides[i], pads[i], training)
                 z, c = _bn_fwd(y, g, b, shortcut if last else None, st, rm, rv, training,

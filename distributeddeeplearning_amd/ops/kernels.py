@@ -295,10 +295,12 @@ def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):
           "bn_eval_coeffs")
 
 
-def bn_apply_fwd(y, scale, shift, res, z, M, C, relu):
-    f = _fn("ddl_bn_apply_fwd", "ppppp qii p")
-    check(f(y.data_ptr(), _p(scale), _p(shift), _p(res), z.data_ptr(), M, C,
-            1 if relu else 0, _raw_stream()), "bn_apply_fwd")
+def bn_apply_fwd(y, scale, shift, res, z, M, C, relu, res_scale=None, res_shift=None):
+    """z = act(y*scale + shift [+ res]); with ``res_scale``/``res_shift`` the residual is the raw
+    output of the projection conv and its BatchNorm is applied on the fly."""
+    f = _fn("ddl_bn_apply_fwd_ex", "ppppppp qii p")
+    check(f(y.data_ptr(), _p(scale), _p(shift), _p(res), _p(res_scale), _p(res_shift),
+            z.data_ptr(), M, C, 1 if relu else 0, _raw_stream()), "bn_apply_fwd")
 
 
 @functools.lru_cache(maxsize=None)

@@ -1,4 +1,5 @@
 #!/bin/bash
 set -o pipefail
-timeout -k 10 300 python -u -m pytest tests/test_gpu_kernels.py -x -q -k "graphed or fused_sgd or lars" --timeout 200 --timeout-method thread 2>&1 | tail -30 || exit 1
-timeout -k 10 200 python -u bench.py --graph 2>&1 | tail -3 || exit 1
+export TMPDIR=/tmp
+cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_ds -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/prof_ds.log 2>&1 || { tail -30 $GRAFT_REPO_ROOT/gpurun_out/prof_ds.log; exit 1; }
+echo profiled
