@@ -312,6 +312,23 @@ extern "C" int ddl_stream_priority_range(int* least, int* greatest) {
     return hipDeviceGetStreamPriorityRange(least, greatest) == hipSuccess ? DDL_OK : DDL_ELAUNCH;
 }
 
+// Event helpers for the two-stream backward (ops/hip_ops.py): one ctypes call orders `waiter`
+// after everything queued on `producer` so far.  The event may be reused: a wait refers to the
+// record that preceded it, later records do not disturb it.
+extern "C" int ddl_event_create(void** out) {
+    hipEvent_t e = nullptr;
+    if (!out || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DDL_ELAUNCH;
+    *out = (void*)e;
+    return DDL_OK;
+}
+
+extern "C" int ddl_stream_wait_stream(void* waiter, void* producer, void* event) {
+    if (!event) return DDL_EINVAL;
+    if (hipEventRecord((hipEvent_t)event, (hipStream_t)producer) != hipSuccess) return DDL_ELAUNCH;
+    if (hipStreamWaitEvent((hipStream_t)waiter, (hipEvent_t)event, 0) != hipSuccess) return DDL_ELAUNCH;
+    return DDL_OK;
+}
+
 extern "C" int ddl_stream_create(int priority, void** out) {
     hipStream_t s = nullptr;
     if (!out || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) return DDL_ELAUNCH;

@@ -143,17 +143,23 @@ def _is_stem(w, stride, padding):
 
 
 def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho, Wo, n_valid=None,
-                accumulate=False):
+                accumulate=False, stream=None, workspace=None):
     """Backward-weights: split-K partials then ordered reduction into a tensor shaped like
-    ``w_like`` (memory [K][R][S][C])."""
+    ``w_like`` (memory [K][R][S][C]).  ``stream`` (raw handle) / ``workspace`` (callable: bytes ->
+    device address valid on that stream): the side-stream path, which neither switches torch's
+    current stream nor allocates."""
     B, Hin, Win, C = geom[0], geom[1], geom[2], geom[3]
     M = B * Ho * Wo
     splits = K.conv_wgrad_splits(M, Kc, C, R, S)
     slab = Kc * R * S * C
-    partial = torch.empty((splits, slab), dtype=torch.float32, device=dy.device)
-    K.conv_wgrad(dy, x_ptr_tensor, geom, partial, Kc, R, S, stride, pad, pad_w, Ho, Wo, splits)
+    if workspace is None:
+        partial = torch.empty((splits, slab), dtype=torch.float32, device=dy.device)
+    else:
+        partial = workspace(4 * splits * slab)
+    K.conv_wgrad(dy, x_ptr_tensor, geom, partial, Kc, R, S, stride, pad, pad_w, Ho, Wo, splits,
+                 stream=stream)
     n = slab if n_valid is None else n_valid
-    K.splitk_reduce(partial, w_like, n, splits, slab, accumulate)
+    K.splitk_reduce(partial, w_like, n, splits, slab, accumulate, stream=stream)
     return w_like
 
 
@@ -287,10 +293,13 @@ def _conv_wgrad(dy, x, w, stride, padding):
             _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
                         accumulate=True)
         else:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                            accumulate=True)
+            # raw event + raw stream handle: no torch stream context, no torch Event objects and a
+            # persistent partial-sum workspace (side-stream kernels run in order, one buffer
+            # serves them all) - ~25 us of host time per weight gradient less
+            raw = side.cuda_stream
+            K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
+            _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
+                        accumulate=True, stream=raw, workspace=_side_workspace)
             # the caching allocator must not hand these blocks out again before the side stream
             # is done with them
             dy.record_stream(side)
@@ -303,7 +312,19 @@ def _conv_wgrad(dy, x, w, stride, padding):
 
 
 # ---- second stream for weight gradients --------------------------------------------------------
-_SIDE = {"on": True, "stream": None, "pending": False}
+_SIDE = {"on": True, "stream": None, "pending": False, "event": None, "ws": None}
+
+
+def _side_workspace(nbytes):
+    """Address of the side stream's split-K workspace (grown on demand; allocated under the side
+    stream so that the allocator recycles a replaced buffer in that stream's order)."""
+    ws = _SIDE["ws"]
+    if ws is None or ws.numel() < nbytes:
+        side = _SIDE["stream"]
+        with torch.cuda.stream(side):
+            ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=side.device)
+        _SIDE["ws"] = ws
+    return ws.data_ptr()
 
 
 def set_wgrad_side_stream(on: bool):
@@ -330,7 +351,10 @@ def _side_stream(device):
                 if want is None:
                     want = int(prio)
                 st = torch.cuda.ExternalStream(K.create_stream(want), device=device)
+        with torch.cuda.device(device):
+            _SIDE["event"] = K.create_event()
         _SIDE["stream"] = st
+        _SIDE["ws"] = None
     return st
 
 

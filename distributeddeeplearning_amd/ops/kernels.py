@@ -100,6 +100,19 @@ def create_stream(priority: int) -> int:
     return h.value
 
 
+def create_event() -> int:
+    """A timing-less HIP event (process lifetime) for :func:`stream_wait_stream`."""
+    h = ctypes.c_void_p()
+    check(lib().ddl_event_create(ctypes.byref(h)), "hipEventCreate")
+    return h.value
+
+
+def stream_wait_stream(waiter: int, producer: int, event: int) -> None:
+    """Order raw stream ``waiter`` after the work queued on raw stream ``producer`` so far."""
+    f = _fn("ddl_stream_wait_stream", "ppp")
+    check(f(waiter, producer, event), "stream_wait_stream")
+
+
 def ptr(t) -> ctypes.c_void_p:
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -251,19 +264,21 @@ def conv_wgrad_splits(M, K, C, R, S):
     return int(lib().ddl_conv_wgrad_splits(_i64(M), _i32(K), _i32(C), _i32(R), _i32(S)))
 
 
-def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hout, Wout, splits):
+def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hout, Wout, splits,
+               stream=None):
+    """``partial``: tensor or raw address; ``stream``: raw HIP stream (default: current)."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
     f = _fn("ddl_conv_wgrad", "ppp qq iiii qqq iiiiiiiii p")
-    check(f(dy.data_ptr(), x_ptr_tensor.data_ptr(), partial.data_ptr(), dy.numel(), xn, B, Hin, Win,
-            C, sb, sh, sw, Hout, Wout, K, R, S, stride, pad, pad_w, splits, _raw_stream()),
-          "conv_wgrad")
+    check(f(dy.data_ptr(), x_ptr_tensor.data_ptr(), _p(partial), dy.numel(), xn, B, Hin, Win,
+            C, sb, sh, sw, Hout, Wout, K, R, S, stride, pad, pad_w, splits,
+            _raw_stream() if stream is None else stream), "conv_wgrad")
 
 
-def splitk_reduce(partial, out, n, splits, slab, accumulate=False):
+def splitk_reduce(partial, out, n, splits, slab, accumulate=False, stream=None):
     f = _fn("ddl_splitk_reduce", "pp qiq ii p")
-    check(f(partial.data_ptr(), out.data_ptr(), n, splits, slab,
-            1 if out.dtype == torch.bfloat16 else 0, 1 if accumulate else 0, _raw_stream()),
-          "splitk_reduce")
+    check(f(_p(partial), out.data_ptr(), n, splits, slab,
+            1 if out.dtype == torch.bfloat16 else 0, 1 if accumulate else 0,
+            _raw_stream() if stream is None else stream), "splitk_reduce")
 
 
 # ---- batch norm / pooling / loss (csrc/kernels/nn_kernels.hip) -------------------------------
