@@ -1,5 +1,5 @@
 #!/bin/bash
-# secondary BASELINE configs on one GPU: large per-GPU batch (LARS / SGD), ResNet-152, forced exchange
+# secondary configurations on one GPU: other depths, larger per-GPU batches, LARS, forced exchange
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -10,9 +10,15 @@ run() {
   timeout -k 10 300 "$@" > gpurun_out/configs_last.log 2>&1 || { tail -30 gpurun_out/configs_last.log; exit 1; }
   tail -1 gpurun_out/configs_last.log | tee -a $out
 }
-run python -u bench.py --batch 1024 --optimizer lars --steps 8 --warmup 3
+run python -u bench.py
+run python -u bench.py --optimizer lars
+run python -u bench.py --batch 512 --steps 16 --warmup 4
 run python -u bench.py --batch 1024 --steps 8 --warmup 3
-run python -u bench.py --model resnet152 --steps 12 --warmup 4
-run python -u bench.py --optimizer lars --steps 20 --warmup 5
-run env HVD_FORCE_COLLECTIVES=1 python -u bench.py --model resnet152 --steps 12 --warmup 4
-rocm-smi --showmeminfo vram 2>/dev/null | tail -4 | tee -a $out
+run python -u bench.py --batch 1024 --optimizer lars --steps 8 --warmup 3
+run python -u bench.py --model resnet18
+run python -u bench.py --model resnet34
+run python -u bench.py --model resnet101 --steps 15 --warmup 5
+run python -u bench.py --model resnet152 --steps 15 --warmup 5
+run python -u bench.py --model resnet200 --steps 10 --warmup 4
+run env HVD_FORCE_COLLECTIVES=1 python -u bench.py
+run env HVD_FORCE_COLLECTIVES=1 python -u bench.py --model resnet152 --steps 15 --warmup 5
