@@ -56,6 +56,8 @@ CONV_CASES = [
     (2, 32, 9, 11, 96, 3, 1, 1),      # BK=32 path, odd sizes, Cout not a tile multiple
     (2, 64, 15, 15, 64, 3, 2, 1),     # stride 2 with odd extent: dilated (non-parity) dgrad path
     (3, 64, 10, 12, 128, 1, 2, 0),    # 1x1 stride 2, parity dgrad with empty tap classes
+    (65, 128, 28, 27, 256, 3, 1, 1),  # 256x128 block tile (N >= 256, R*S*C >= 1024, >= 384 tiles), ragged last tile
+    (96, 1024, 23, 23, 256, 1, 1, 0), # 256x128 tile, 1x1 (fwd); its dgrad (N = 1024, C = 256) stays on 128x128
 ]
 
 
@@ -276,7 +278,8 @@ def test_bottleneck_block_matches_fp32_reference():
 
 
 @pytest.mark.parametrize("case", [(4, 128, 28, 28, 128, 3, 1, 1), (3, 128, 28, 28, 128, 3, 2, 1),
-                                  (5, 64, 14, 14, 256, 1, 1, 0), (2, 64, 15, 15, 64, 3, 2, 1)])
+                                  (5, 64, 14, 14, 256, 1, 1, 0), (2, 64, 15, 15, 64, 3, 2, 1),
+                                  (65, 256, 28, 27, 128, 3, 1, 1)])  # last: 256x128 tile dgrad
 def test_dgrad_fused_bn_reduce_and_relu_mask_epilogues(case):
     """EPI 2 (masked gradient + BatchNorm-backward partial sums) and EPI 3 (ReLU pre-mask) of the
     backward-data kernel against the unfused kernel followed by plain tensor math."""
