@@ -56,6 +56,7 @@ def build_kernels(force=False, jobs=8, verbose=True):
     hipcc = _hipcc()
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-math-errno", "-ffp-contract=fast",
              "-fno-gpu-sanitize", "-Wno-unused-result", "-I", os.path.join(ROOT, "csrc", "kernels")]
+    flags += os.environ.get("DDL_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DDDL_CONV_PROBES (timing probes)
     todo, objs = [], []
     for s in srcs:
         o = os.path.join(BUILD, "kernels", os.path.basename(s) + ".o")

@@ -37,6 +37,8 @@ struct IGemmParams {
     int Hout, Wout, N, M;
     int R, S, ostride, pad, pad_w, idil_log2;
     int tiles_m, tiles_n;
+    unsigned long long* dbg;  // probe builds: [block][8] cycle stamps of wave 0
+    int probe;             // timing-only probes (DDL_CONV_PROBE): 4 no MFMA, 8 no LDS stores, 16 no LDS fragment reads, 32 no barrier
     int stat_rows;         // rows of `stats`: one per 128 output rows (a 256-row tile writes two)
     int addend_sub2;  // addend is [B][Hout/2][Wout/2][N]: added at even (h, w) pixels only
     int parity, tiles_per_class, Mc;  // stride-2 backward-data: M ordered by output-pixel parity class
@@ -77,6 +79,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
+#ifdef DDL_CONV_PROBES
+    unsigned long long stamp[12];
+    for (int i = 0; i < 12; ++i) stamp[i] = 0;
+#define DDL_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    DDL_STAMP(0);
+#else
+#define DDL_STAMP(i) do { } while (0)
+#endif
 
     // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
     // contiguous run of logical tiles, n fastest, so the A panel of an M tile is reused in L2.
@@ -190,18 +200,39 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
+#ifdef DDL_CONV_PROBES
+    const __bf16 probe_seed = (__bf16)(float)(p.M & 3);
+#endif
     auto compute = [&](int stage) {
         const unsigned char* As = smem + stage * STAGE;
         const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 xa[FM], wb[FN];
+#ifdef DDL_CONV_PROBES
+            if (p.probe & 16) {
+#pragma unroll
+                for (int j = 0; j < FM; ++j) xa[j] = (bf16x8)(probe_seed + j);
+#pragma unroll
+                for (int i = 0; i < FN; ++i) wb[i] = (bf16x8)(probe_seed + i);
+            } else
+#endif
+            {
 #pragma unroll
             for (int j = 0; j < FM; ++j)
                 xa[j] = *reinterpret_cast<const bf16x8*>(As + lds_off<BK>(wm * WM + j * 16 + fr, kk * 4 + fq));
 #pragma unroll
             for (int i = 0; i < FN; ++i)
                 wb[i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * WN + i * 16 + fr, kk * 4 + fq));
+            }
+#ifdef DDL_CONV_PROBES
+            if (p.probe & 4) {
+#pragma unroll
+                for (int i = 0; i < FN; ++i)
+#pragma unroll
+                    for (int j = 0; j < FM; ++j) { acc[i][j][0] += (float)wb[i][0] * (float)xa[j][0]; }
+            } else
+#endif
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -213,19 +244,43 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     // one tile of loads in flight per block (a second register set was measured: the extra
     // VGPRs cost more occupancy than the deeper prefetch returned — profiles/r1_notes.md)
     u32x4 a0[A_LOADS], b0[B_LOADS];
+    DDL_STAMP(1);
     if (KT > 0) {
         fetch(a0, b0);
         stash(0, a0, b0);
     }
     __syncthreads();
+    DDL_STAMP(2);
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
+#if defined(DDL_CONV_PROBES) && DDL_CONV_PROBES >= 2
+        const bool mid = kt == (KT >> 1);
+        if (mid) DDL_STAMP(5);
+        if (kt + 1 < KT) fetch(a0, b0);
+        if (mid) DDL_STAMP(6);
+        compute(cur);
+        if (mid) DDL_STAMP(7);
+        if (kt + 1 < KT) stash(cur ^ 1, a0, b0);
+        if (mid) DDL_STAMP(8);
+        __syncthreads();
+        if (mid) DDL_STAMP(9);
+        continue;
+#endif
         if (kt + 1 < KT) fetch(a0, b0);
         compute(cur);
+#ifdef DDL_CONV_PROBES
+        if (p.probe & 8) {  // keep the loads alive without the LDS stores
+            if (kt + 1 < KT && a0[0][0] == 0x12345678u && b0[0][0] == 0x9abcdef0u) stash(cur ^ 1, a0, b0);
+        } else
+#endif
         if (kt + 1 < KT) stash(cur ^ 1, a0, b0);
+#ifdef DDL_CONV_PROBES
+        if (!(p.probe & 32))
+#endif
         __syncthreads();
     }
 
+    DDL_STAMP(3);
     // ---- epilogue: acc -> bf16 tile in LDS ([BM][BN], row stride OSTR) -> coalesced stores ----
     unsigned char* Os = smem;
 #pragma unroll
@@ -359,6 +414,20 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
         }
         if (STATS && (it0 + BATCH) % SUB_ITERS == 0) emit_stats((it0 + BATCH) / SUB_ITERS - 1);
     }
+#ifdef DDL_CONV_PROBES
+    DDL_STAMP(4);
+    if (p.dbg && tid == 0) {
+        unsigned long long* d = p.dbg + (long long)blockIdx.x * 8;
+        d[0] = stamp[1] - stamp[0];   // prologue (address setup)
+        d[1] = stamp[2] - stamp[1];   // first tile fetch + stash + barrier
+        d[2] = stamp[3] - stamp[2];   // main loop
+        d[3] = stamp[4] - stamp[3];   // epilogue
+        d[4] = stamp[6] - stamp[5];   // mid iteration: fetch issue
+        d[5] = stamp[7] - stamp[6];   //                compute (LDS reads + MFMA issue)
+        d[6] = stamp[8] - stamp[7];   //                wait for loads + LDS stores
+        d[7] = stamp[9] - stamp[8];   //                barrier
+    }
+#endif
 }
 
 template <int BM, int BN, int BK>
@@ -378,6 +447,10 @@ int launch_cfg(const IGemmParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+static unsigned long long* g_conv_dbg = nullptr;
+// probe builds (-DDDL_CONV_PROBES): every launch writes [block][8] cycle stamps of wave 0 here
+extern "C" void ddl_conv_set_debug_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; }
 
 // Number of M tiles the forward kernel uses for a problem (so callers can size `stats`).
 extern "C" int ddl_conv_igemm_tiles_m(long long M) { return (int)((M + 127) / 128); }
@@ -427,6 +500,13 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
     p.addend = (const bf16_t*)addend; p.stats = (float*)stats;
     p.ep_y = (const bf16_t*)ep_y; p.ep_fcoef = (const float*)ep_fcoef; p.ep_mask = (const bf16_t*)ep_mask;
     p.x_bytes = (unsigned)(x_numel * 2); p.w_bytes = (unsigned)(w_numel * 2);
+    // timing-only probe (results are wrong): a descriptor with zero records drops every load through
+    // it while the instruction stream, waits and barriers stay - prices one operand's traffic
+    static const int probe = getenv("DDL_CONV_PROBE") ? atoi(getenv("DDL_CONV_PROBE")) : 0;
+    if (probe & 1) p.x_bytes = 0;
+    if (probe & 2) p.w_bytes = 0;
+    p.probe = probe;
+    p.dbg = g_conv_dbg;
     p.Hin = Hin; p.Win = Win; p.C = C; p.xs_b = xs_b; p.xs_h = xs_h; p.xs_w = xs_w;
     p.Hout = Hout; p.Wout = Wout; p.N = N; p.M = (int)M;
     p.R = R; p.S = S; p.ostride = ostride; p.pad = pad; p.pad_w = pad_w;
