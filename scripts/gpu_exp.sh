@@ -1,8 +1,7 @@
 #!/bin/bash
-# phase probes of the conv main loop (library built with -DDDL_CONV_PROBES; results are wrong, timing only)
-# bits: 1 no activation loads, 2 no weight loads, 4 no MFMA, 8 no LDS stores, 16 no LDS fragment reads, 32 no barrier
 set -o pipefail
-for pr in 0 3 7 11 19 15 27 23 31 35 63; do
-  echo "== DDL_CONV_PROBE=$pr"
-  DDL_CONV_BM=128 DDL_CONV_PROBE=$pr timeout -k 10 200 python -u benchmarks/kernel_bench.py --iters 20 --only c4,d1 2>&1 | grep "^c4\|^d1" | cut -c1-60 || exit 1
+timeout -k 10 400 python -u -m pytest tests/test_gpu_kernels.py -x -q --timeout 200 --timeout-method thread 2>&1 | tail -2 || exit 1
+timeout -k 10 200 python -u benchmarks/kernel_bench.py --iters 20 --only a1,a2,a4,b1,b3,b5,c1,c3,c5,d1,d3,d5 2>&1 | grep -v amdgpu.ids | cut -c1-100 || exit 1
+for i in 1 2; do
+  timeout -k 10 200 python -u bench.py 2>&1 | tail -1 | grep -o "ms_per_step\": [0-9.]*" | tr '\n' ' ' || exit 1
 done
