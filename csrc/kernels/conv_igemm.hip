@@ -12,11 +12,13 @@
 //     "CRSK") with ostride = 1 and input dilation idil = forward stride.
 //
 // Structure (CDNA4): 256 threads = 4 waves (2 x 2), block tile BM x BN x BK, wave tile
-// BM/2 x BN/2 of v_mfma_f32_16x16x32_bf16 fragments.  Operand tiles are staged
-// global -> registers (buffer_load_dwordx4: out-of-image taps and M/N edges read as zero through
-// the buffer range check, no branches) -> LDS (XOR-swizzled 16-byte chunks, conflict-free
-// ds_read_b128 fragment reads), double-buffered, one barrier per K tile.  The product is
-// computed swapped (D rows = output channels, D cols = pixels) so each lane owns 4 consecutive
+// BM/2 x BN/2 of v_mfma_f32_16x16x32_bf16 fragments.  Operand tiles go global -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no register stop, out-of-image taps and M/N edges arrive as
+// zeros through the buffer range check, no branches; the XOR swizzle of the 16-byte chunks is
+// applied to the per-lane SOURCE address because the destination is lane-linear), two LDS
+// buffers, one barrier per K tile, conflict-free ds_read_b128 fragment reads.  A register-staged
+// twin of the loop (global -> VGPR -> ds_write_b128) is kept behind DDL_CONV_GLDS=0.  The product
+// is computed swapped (D rows = output channels, D cols = pixels) so each lane owns 4 consecutive
 // channels; the epilogue stages the bf16 tile through LDS and stores whole rows with 16-byte
 // lanes, optionally adding a residual tensor (backward shortcut fusion) and emitting per-tile
 // per-channel sum / sum-of-squares partials for BatchNorm (K6 fused: saves one full read of y).
@@ -62,7 +64,7 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 //      3 backward-data whose consumer is a ReLU: store dz * (mask > 0) so that the consumer's
 //        backward needs neither the mask tensor nor a masked copy of the gradient;
 //      4 = 3 plus the sum g / sum g*y partials of the BatchNorm that feeds that ReLU (ep_y).
-template <int BM, int BN, int BK, int EPI, bool ADDEND>
+template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p) {
     static_assert(BM % 128 == 0, "statistics rows are per 128 output rows");
     constexpr bool STATS = EPI == 1 || EPI == 2 || EPI == 4;
@@ -119,7 +121,12 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 
-    const int ch = tid % CPR, row0 = tid / CPR;
+    // GLDS (operand tiles by LDS-DMA, `buffer_load_dwordx4 ... lds`): a wave-instruction writes
+    // 64 x 16 bytes at a wave-uniform LDS base + lane * 16, so the swizzle moves to the SOURCE side:
+    // the lane at physical chunk position `chp` of its row fetches logical chunk chp ^ f(row)
+    // (f only depends on row bits that the per-slot row stride RPP leaves alone).
+    const int chp = tid % CPR, row0 = tid / CPR;
+    const int ch = !GLDS ? chp : (BK == 64 ? (chp ^ (row0 & 7)) : (chp ^ ((0 - (row0 >> 2)) & 3)));
     const int Kdim = p.R * p.S * p.C;
     // per-row A state
     long long a_base[A_LOADS];
@@ -198,6 +205,22 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
             *reinterpret_cast<u32x4*>(Bs + lds_off<BK>(row0 + i * RPP, ch)) = br[i];
     };
 
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+    auto fetch_lds = [&](int stage) {   // GLDS: global -> LDS without a register stop
+        if (kc == 0) retap();
+        const int kco = kc * (BK * 2);
+        unsigned char* As = smem + stage * STAGE + wid * (64 / CPR) * (BK * 2);
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(As + i * RPP * (BK * 2)), 16, (int)a_voff[i], kco, 0, 0);
+        const int wk = ((kr * p.S + ks) * p.C + kc * BK) * 2;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(Bs + i * RPP * (BK * 2)), 16, (int)b_off[i], wk, 0, 0);
+        if (++kc == cpt) { kc = 0; ks += tstep; if (ks >= p.S) { ks = s0; kr += tstep; } }
+    };
+
     f32x4 acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; ++i)
@@ -246,10 +269,25 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
         }
     };
 
-    // one tile of loads in flight per block (a second register set was measured: the extra
-    // VGPRs cost more occupancy than the deeper prefetch returned — profiles/r1_notes.md)
+    // one tile of loads in flight per block (deeper prefetch measured twice - a second register
+    // set, and a three-buffer LDS-DMA ring with counted vmcnt - and bought nothing at 2-3
+    // workgroups per CU: profiles/r1_notes.md)
     u32x4 a0[A_LOADS], b0[B_LOADS];
     DDL_STAMP(1);
+    if (GLDS) {
+        // two LDS buffers, the next tile's DMA in flight while this tile is consumed; the wait
+        // before the barrier retires it (the barrier then publishes it to the other waves)
+        if (KT > 0) fetch_lds(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) fetch_lds(cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
     if (KT > 0) {
         fetch(a0, b0);
         stash(0, a0, b0);
@@ -283,6 +321,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
         if (!(p.probe & 32))
 #endif
         __syncthreads();
+    }
     }
 
     DDL_STAMP(3);
@@ -435,20 +474,32 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 #endif
 }
 
-template <int BM, int BN, int BK>
-int launch_cfg(const IGemmParams& p, hipStream_t stream) {
+template <int BM, int BN, int BK, bool GLDS>
+int launch_cfg2(const IGemmParams& p, hipStream_t stream) {
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     static const int extra_lds = getenv("DDL_CONV_EXTRA_LDS") ? atoi(getenv("DDL_CONV_EXTRA_LDS")) : 0;  // occupancy probe
     if (p.stats && p.addend && !(p.ep_y && p.ep_mask)) return DDL_EINVAL;
-    if (p.ep_y && p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, true>), grid, block, extra_lds, stream, p);
-    else if (p.ep_y && p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, false>), grid, block, extra_lds, stream, p);
-    else if (p.ep_y) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 2, false>), grid, block, extra_lds, stream, p);
-    else if (p.ep_mask && p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, true>), grid, block, extra_lds, stream, p);
-    else if (p.ep_mask) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 3, false>), grid, block, extra_lds, stream, p);
-    else if (p.stats) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 1, false>), grid, block, extra_lds, stream, p);
-    else if (p.addend) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, true>), grid, block, extra_lds, stream, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, false>), grid, block, extra_lds, stream, p);
+#define DDL_LAUNCH(E, A) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, E, A, GLDS>), grid, block, extra_lds, stream, p)
+    if (p.ep_y && p.ep_mask && p.addend) DDL_LAUNCH(4, true);
+    else if (p.ep_y && p.ep_mask) DDL_LAUNCH(4, false);
+    else if (p.ep_y) DDL_LAUNCH(2, false);
+    else if (p.ep_mask && p.addend) DDL_LAUNCH(3, true);
+    else if (p.ep_mask) DDL_LAUNCH(3, false);
+    else if (p.stats) DDL_LAUNCH(1, false);
+    else if (p.addend) DDL_LAUNCH(0, true);
+    else DDL_LAUNCH(0, false);
+#undef DDL_LAUNCH
     return ddl_launch_status();
+}
+
+template <int BM, int BN, int BK>
+int launch_cfg(const IGemmParams& p, hipStream_t stream) {
+    // Operand tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no VGPR stop, no
+    // ds_write pass (13 cycles per wave-instruction) - count-weighted fwd 3.74 -> 3.58 ms, dgrad
+    // 3.47 -> 3.28 ms, the BK=64 tiles gain most (d4 3x3 512 @7: 78 -> 61 us = 974 TFLOP/s).
+    // DDL_CONV_GLDS=0 selects the register-staged path (global -> VGPR -> ds_write_b128).
+    static const int glds = getenv("DDL_CONV_GLDS") ? atoi(getenv("DDL_CONV_GLDS")) : 1;  // tuning knob
+    return glds ? launch_cfg2<BM, BN, BK, true>(p, stream) : launch_cfg2<BM, BN, BK, false>(p, stream);
 }
 
 }  // namespace
