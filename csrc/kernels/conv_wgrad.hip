@@ -47,10 +47,20 @@ __device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r)
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
-template <int BMw, int BNw, bool SIMPLE, bool UNITAP>
+// swizzle of the LDS-DMA image: 32-byte window w of row r is stored at window w ^ lds_swz(r), so
+// that the 8 rows one half-wave's transposing read touches fall into 8 distinct 32-byte windows of
+// the 256-byte bank row (what the 32-byte row padding does for the register-staged image; an
+// LDS-DMA image cannot be padded, its wave-instruction writes 1 KiB contiguously)
+template <int ROW_BYTES>
+__device__ __forceinline__ int lds_swz(int row) {
+    return ROW_BYTES == 256 ? (row & 7) : ((row >> 1) & 3);
+}
+
+template <int BMw, int BNw, bool SIMPLE, bool UNITAP, bool GLDS>
 __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p) {
+    static_assert(!GLDS || ((BMw == 64 || BMw == 128) && (BNw == 64 || BNw == 128)), "LDS-DMA image: 128- or 256-byte rows");
     constexpr int BK = 32;                          // reduction rows per tile
-    constexpr int A_STR = BMw * 2 + 32, B_STR = BNw * 2 + 32;  // padded row strides (bytes)
+    constexpr int A_STR = BMw * 2 + (GLDS ? 0 : 32), B_STR = BNw * 2 + (GLDS ? 0 : 32);  // row strides (bytes)
     constexpr int A_BYTES = BK * A_STR, B_BYTES = BK * B_STR;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int A_CPR = BMw / 8, B_CPR = BNw / 8;
@@ -99,6 +109,7 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     for (int i = 0; i < A_LOADS; ++i) {
         int idx = tid + i * 256;
         int row = idx / A_CPR, ch = idx - row * A_CPR;
+        if (GLDS) ch = (((ch >> 1) ^ lds_swz<BMw * 2>(row)) << 1) | (ch & 1);  // physical position -> logical chunk
         int n = n0 + ch * 8;
         a_voff[i] = (row < BK && n < p.K) ? ((unsigned)(m_begin + row) * (unsigned)p.K + (unsigned)n) * 2u : INVALID;
     }
@@ -108,6 +119,7 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     for (int i = 0; i < B_LOADS; ++i) {
         int idx = tid + i * 256;
         int row = idx / B_CPR, ch = idx - row * B_CPR;
+        if (GLDS) ch = (((ch >> 1) ^ lds_swz<BNw * 2>(row)) << 1) | (ch & 1);
         int j = j0 + ch * 8;                      // flattened (r, s, c) index of this 8-channel chunk
         // UNITAP (C is a multiple of BNw): the whole tile belongs to one filter tap
         int tap = (UNITAP ? j0 : j) / p.C, c = j - tap * p.C;
@@ -132,20 +144,29 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     const int xs_w2 = (int)p.xs_w * 2;
     const int row_bytes = p.stride * (int)p.xs_h * 2;              // one output row down, in x bytes
     const int img_bytes = (int)p.xs_b * 2 - p.Hout * row_bytes;    // wrap to the next image
-    auto fetch = [&](int kt) {
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+    // GLDS: the tile goes global -> LDS by LDS-DMA; chunk idx = tid + i*256 of the dense image lands
+    // at byte idx*16, i.e. wave base (wid*64 + i*256)*16 + lane*16
+    auto fetch = [&](int kt, int stage) {
         const int rows_left = m_end - (m_begin + kt * BK);
         const int a_soff = kt * (BK * 2) * p.K;
+        unsigned char* Ad = smem + stage * STAGE + wid * 1024;
+        unsigned char* Bd = Ad + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int row = (tid + i * 256) / A_CPR;
-            a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyr, (int)(row < rows_left ? a_voff[i] : INVALID), a_soff, 0);
+            const int vo = (int)(row < rows_left ? a_voff[i] : INVALID);
+            if (GLDS) __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, (lds_void_ptr)(Ad + i * 4096), 16, vo, a_soff, 0, 0);
+            else a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyr, vo, a_soff, 0);
         }
         if (SIMPLE) {
             const int b_soff = kt * BK * xs_w2;
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
                 const int row = (tid + i * 256) / B_CPR;
-                b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(row < rows_left ? b_base[i] : INVALID), b_soff, 0);
+                const int vo = (int)(row < rows_left ? b_base[i] : INVALID);
+                if (GLDS) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(Bd + i * 4096), 16, vo, b_soff, 0, 0);
+                else b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, b_soff, 0);
             }
         } else {
 #pragma unroll
@@ -153,7 +174,9 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
                 int hi = b_ho[i] * p.stride + b_dh[i], wi = b_wo[i] * p.stride + b_dw[i];
                 const int row = (tid + i * 256) / B_CPR;
                 bool ok = (row < rows_left) & (hi >= 0) & (hi < p.Hin) & (wi >= 0) & (wi < p.Win);
-                b_reg[i] = wg_load16(xr, ok ? b_base[i] + (unsigned)(wi * xs_w2) : INVALID);
+                const unsigned vo = ok ? b_base[i] + (unsigned)(wi * xs_w2) : INVALID;
+                if (GLDS) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(Bd + i * 4096), 16, (int)vo, 0, 0, 0);
+                else b_reg[i] = wg_load16(xr, vo);
                 // advance this slot by BK pixels
                 int wo = b_wo[i] + step_w, ho = b_ho[i] + step_h;
                 unsigned base = b_base[i] + (unsigned)(step_h * row_bytes);
@@ -190,27 +213,30 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
     const int tr_row = 4 * g + q;
 
+    const int swz_a = GLDS ? lds_swz<BMw * 2>(tr_row) : 0, swz_b = GLDS ? lds_swz<BNw * 2>(tr_row) : 0;
     if (KT > 0) {
-        fetch(0);
-        stash(0);
+        fetch(0, 0);
+        if (!GLDS) stash(0);
     }
+    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) fetch(kt + 1);
+        if (kt + 1 < KT) fetch(kt + 1, cur ^ 1);
         unsigned char* As = smem + cur * STAGE;
         unsigned char* Bs = As + A_BYTES;
         bf16x8 af[FM], bfr[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            unsigned char* a0 = As + tr_row * A_STR + (wm * WM + i * 16 + 4 * pq) * 2;
+            // 16 columns = one 32-byte window; GLDS: windows XOR-swizzled per row (rows r and r+16 share the XOR)
+            unsigned char* a0 = As + tr_row * A_STR + ((((wm * WM) >> 4) + i) ^ swz_a) * 32 + 8 * pq;
             bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
             bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 16 * A_STR));
             af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            unsigned char* b0 = Bs + tr_row * B_STR + (wn * WN + j * 16 + 4 * pq) * 2;
+            unsigned char* b0 = Bs + tr_row * B_STR + ((((wn * WN) >> 4) + j) ^ swz_b) * 32 + 8 * pq;
             bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(b0));
             bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(b0 + 16 * B_STR));
             bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -220,7 +246,8 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        if (kt + 1 < KT) stash(cur ^ 1);
+        if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kt + 1 < KT) stash(cur ^ 1);
         __syncthreads();
     }
 
@@ -288,9 +315,22 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
     p.tiles_k = (p.K + BMw - 1) / BMw;
     p.tiles_rsc = (p.R * p.S * p.C + BNw - 1) / BNw;
     dim3 grid(p.tiles_k * p.tiles_rsc * p.splits), block(256);
-    if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true>), grid, block, 0, stream, p);
-    else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false>), grid, block, 0, stream, p);
+    // Operand tiles by LDS-DMA (tile widths 64 / 128 only) for the 3x3 filters: a3 130 -> 120 us,
+    // c4 90 -> 85, d4 86 -> 81; the 1x1 GEMMs (2 workgroups per CU by the split plan) lose 5-15 % with
+    // it and keep the register-staged loop (profiles/r1_notes.md).  DDL_WGRAD_GLDS=0|1 forces.
+    static const int glds_env = getenv("DDL_WGRAD_GLDS") ? atoi(getenv("DDL_WGRAD_GLDS")) : -1;  // tuning knob
+    constexpr bool CAN = (BMw == 64 || BMw == 128) && (BNw == 64 || BNw == 128);
+    if constexpr (CAN) {
+        if (glds_env > 0 || (glds_env < 0 && p.R * p.S >= 9)) {
+            if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true, true>), grid, block, 0, stream, p);
+            else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false, true>), grid, block, 0, stream, p);
+            return ddl_launch_status();
+        }
+    }
+    if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true, false>), grid, block, 0, stream, p);
+    else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false, false>), grid, block, 0, stream, p);
     return ddl_launch_status();
 }
 
