@@ -581,29 +581,37 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
         p.tiles_m = 4 * p.tiles_per_class;
         p.stat_rows = p.tiles_m;
     }
+    // Tile per shape class, from benchmarks/kernel_bench.py sweeps with LDS-DMA staging on MI355X
+    // (profiles/r1_notes.md, r1_kernel_bench_glds_sweep.log).  DDL_CONV_BK=32|64 and
+    // DDL_CONV_BM=128|256 force a variant.
     static const int force_bk = getenv("DDL_CONV_BK") ? atoi(getenv("DDL_CONV_BK")) : 0;  // tuning knob
-    // K-tile depth per shape class, from benchmarks/kernel_bench.py on MI355X (profiles/): the
-    // shallower tile wins (4 blocks per CU instead of 2) except for the deepest reductions
-    const bool deep = (R * S == 1) ? (C >= 2048) : (C < 128 || C >= 512);
-    const bool bk64 = (C % 64 == 0) && force_bk != 32 && (force_bk == 64 || deep);
+    static const int force_bm = getenv("DDL_CONV_BM") ? atoi(getenv("DDL_CONV_BM")) : 0;  // tuning knob
+    const long long RSC = (long long)R * S * C;
+    // BK = 64 (one barrier per 64 reduction elements, 64 KB of LDS per workgroup): every 3x3 (the
+    // parity-ordered stride-2 backward only from 512 channels), 1x1 from 2048 channels, and the
+    // narrow-output 1x1 (N <= 64) from 256
+    bool deep = (R * S == 1) ? (C >= 2048 || (N <= 64 && C >= 256)) : (p.parity ? C >= 512 : true);
+    // 256x128 block tile, BK = 32 (wave tile 128x64: a quarter fewer LDS and L2->LDS bytes per FLOP)
+    // for exactly two N tiles sharing the A panel, a long reduction and enough tiles to fill the
+    // chip: c4 3x3 256->256 @14 fwd 71 (BK=64) -> 65 us, dgrad 68 -> 62 us.  With more N tiles, short
+    // reductions or < 1.5 tiles per CU it loses (no stream-K here).
+    const long long tiles256 = ((M + 255) / 256) * ((N + 127) / 128);
+    bool big = !p.parity && N >= 256 && N < 512 && RSC >= 1024 && tiles256 >= 384;
+    if (force_bm == 128) big = false;
+    if (force_bm == 256 && !p.parity && N > 64) big = true;
+    if (force_bk == 32) deep = false;
+    if (force_bk == 64) deep = true;
+    if (C % 64) deep = false;
     if (N <= 64) {
         p.tiles_n = (N + 63) / 64;
-        return bk64 ? launch_cfg<128, 64, 64>(p, stream) : launch_cfg<128, 64, 32>(p, stream);
+        return deep ? launch_cfg<128, 64, 64>(p, stream) : launch_cfg<128, 64, 32>(p, stream);
     }
     p.tiles_n = (N + 127) / 128;
-    // 256x128 block tile (wave tile 128x64: a quarter fewer LDS and L2->LDS bytes per FLOP) where the
-    // reduction is long, two or more N tiles share the A panel and enough tiles remain to fill the
-    // chip: c4 3x3 256->256 @14 fwd 88 -> 74 us, dgrad 85 -> 70 us (805-840 TFLOP/s); c3 1x1
-    // 1024->256 fwd 45 -> 39 us; loses on short reductions and where < 1.5 tiles per CU are left
-    // (profiles/r1_notes.md).  DDL_CONV_BM=128|256 forces one or the other.
-    static const int force_bm = getenv("DDL_CONV_BM") ? atoi(getenv("DDL_CONV_BM")) : 0;  // tuning knob
-    const long long tiles256 = ((M + 255) / 256) * p.tiles_n;
-    const bool big = force_bm == 256 || (force_bm != 128 && !bk64 && N >= 256 && (long long)R * S * C >= 1024 && tiles256 >= 384);
-    if (big && !p.parity) {
+    if (big) {
         p.tiles_m = (int)((M + 255) / 256);
-        return bk64 ? launch_cfg<256, 128, 64>(p, stream) : launch_cfg<256, 128, 32>(p, stream);
+        return (deep && force_bk == 64) ? launch_cfg<256, 128, 64>(p, stream) : launch_cfg<256, 128, 32>(p, stream);
     }
-    return bk64 ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
+    return deep ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
 }
 
 extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void* addend, void* stats,
