@@ -61,10 +61,15 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--device", default=None, help="cuda|cpu (default: cuda when available)")
     ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--stall-watch", type=float, default=0.0, metavar="SECONDS",
+                    help="diagnostic: dump every thread's stack to stderr when one step takes longer than this")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one HIP graph after the first warm-up steps "
                          "(training/graph.py); needs --warmup >= 2")
     return ap.parse_args(argv)
+
+
+_T_START = time.perf_counter()
 
 
 def main(argv=None):
@@ -121,6 +126,32 @@ def main(argv=None):
         if use_cuda:
             torch.cuda.synchronize()
 
+    if args.stall_watch > 0:
+        import faulthandler
+
+        plain_step = one_step
+
+        counter = {"step": 0}
+
+        def one_step():  # noqa: F811 - diagnostic wrapper
+            faulthandler.dump_traceback_later(args.stall_watch, exit=False)
+            ms0 = torch.cuda.memory_stats() if use_cuda else {}
+            t_s = time.perf_counter()
+            out = plain_step()
+            faulthandler.cancel_dump_traceback_later()
+            dt = time.perf_counter() - t_s
+            counter["step"] += 1
+            if dt > args.stall_watch:
+                ms1 = torch.cuda.memory_stats() if use_cuda else {}
+                keys = ("segment.all.allocated", "segment.all.freed", "num_alloc_retries", "num_device_alloc",
+                        "num_device_free", "num_sync_all_streams")
+                delta = {k: ms1.get(k, 0) - ms0.get(k, 0) for k in keys}
+                print("stall-watch: step %d took %.3f s on the host (%.2f s after start); allocator deltas %s; "
+                      "reserved %.1f GB" % (counter["step"], dt, time.perf_counter() - _T_START, delta,
+                                            ms1.get("reserved_bytes.all.current", 0) / 2 ** 30),
+                      file=sys.stderr, flush=True)
+            return out
+
     loss = None
     for _ in range(args.warmup):
         loss = one_step()
@@ -166,6 +197,7 @@ def main(argv=None):
             "final_loss": round(final_loss, 4),
             "ops_backend": "hip" if (use_cuda and ops.backend() != "aten") else "aten",
             "hip_graph": bool(graphed is not None and graphed.graphed),
+            "reserved_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1) if use_cuda else 0.0,
             "config": {"model": args.model, "global_batch": global_batch,
                        "per_gpu_batch": args.batch, "image": args.image,
                        "optimizer": args.optimizer, "parallelism": "dp%d" % world},

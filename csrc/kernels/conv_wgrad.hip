@@ -56,10 +56,10 @@ __device__ __forceinline__ int lds_swz(int row) {
     return ROW_BYTES == 256 ? (row & 7) : ((row >> 1) & 3);
 }
 
-template <int BMw, int BNw, bool SIMPLE, bool UNITAP, bool GLDS>
+template <int BMw, int BNw, bool SIMPLE, bool UNITAP, bool GLDS, int BK = 32>
 __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p) {
     static_assert(!GLDS || ((BMw == 64 || BMw == 128) && (BNw == 64 || BNw == 128)), "LDS-DMA image: 128- or 256-byte rows");
-    constexpr int BK = 32;                          // reduction rows per tile
+    static_assert(BK == 32 || (BK == 64 && GLDS), "64 reduction rows per tile only with LDS-DMA staging (no staging registers)");
     constexpr int A_STR = BMw * 2 + (GLDS ? 0 : 32), B_STR = BNw * 2 + (GLDS ? 0 : 32);  // row strides (bytes)
     constexpr int A_BYTES = BK * A_STR, B_BYTES = BK * B_STR;
     constexpr int STAGE = A_BYTES + B_BYTES;
@@ -225,18 +225,20 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
         if (kt + 1 < KT) fetch(kt + 1, cur ^ 1);
         unsigned char* As = smem + cur * STAGE;
         unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {   // 32 reduction rows per MFMA step (rows r and r+32 share the XOR too)
         bf16x8 af[FM], bfr[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             // 16 columns = one 32-byte window; GLDS: windows XOR-swizzled per row (rows r and r+16 share the XOR)
-            unsigned char* a0 = As + tr_row * A_STR + ((((wm * WM) >> 4) + i) ^ swz_a) * 32 + 8 * pq;
+            unsigned char* a0 = As + (tr_row + kk * 32) * A_STR + ((((wm * WM) >> 4) + i) ^ swz_a) * 32 + 8 * pq;
             bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
             bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 16 * A_STR));
             af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            unsigned char* b0 = Bs + tr_row * B_STR + ((((wn * WN) >> 4) + j) ^ swz_b) * 32 + 8 * pq;
+            unsigned char* b0 = Bs + (tr_row + kk * 32) * B_STR + ((((wn * WN) >> 4) + j) ^ swz_b) * 32 + 8 * pq;
             bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(b0));
             bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(b0 + 16 * B_STR));
             bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -246,6 +248,7 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
         if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (kt + 1 < KT) stash(cur ^ 1);
         __syncthreads();
@@ -315,13 +318,26 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
     p.tiles_k = (p.K + BMw - 1) / BMw;
     p.tiles_rsc = (p.R * p.S * p.C + BNw - 1) / BNw;
     dim3 grid(p.tiles_k * p.tiles_rsc * p.splits), block(256);
-    // Operand tiles by LDS-DMA (tile widths 64 / 128 only) for the 3x3 filters: a3 130 -> 120 us,
-    // c4 90 -> 85, d4 86 -> 81; the 1x1 GEMMs (2 workgroups per CU by the split plan) lose 5-15 % with
-    // it and keep the register-staged loop (profiles/r1_notes.md).  DDL_WGRAD_GLDS=0|1 forces.
+    // Operand tiles by LDS-DMA (tile widths 64 / 128 only), per class (kernel_bench.py sweeps,
+    // profiles/r1_notes.md): 3x3 filters with 32 reduction rows per tile (a3 130 -> 120 us, c4 90 -> 85);
+    // 1x1 GEMMs with >= 128 channels on both sides with 64 rows per tile (half the barriers: c1
+    // 100 -> 84 us, d1 70 -> 63, b5 57 -> 51; with 32 rows LDS-DMA loses 5-15 % there, with 64 rows the
+    // 3x3 filters lose 10-15 % to the 64 KB of LDS).  The bandwidth-bound 64-channel layers keep the
+    // register-staged loop.  DDL_WGRAD_GLDS=0|1 and DDL_WGRAD_BK=32|64 force.
     static const int glds_env = getenv("DDL_WGRAD_GLDS") ? atoi(getenv("DDL_WGRAD_GLDS")) : -1;  // tuning knob
+    static const int bk_env = getenv("DDL_WGRAD_BK") ? atoi(getenv("DDL_WGRAD_BK")) : 0;         // tuning knob
     constexpr bool CAN = (BMw == 64 || BMw == 128) && (BNw == 64 || BNw == 128);
     if constexpr (CAN) {
-        if (glds_env > 0 || (glds_env < 0 && p.R * p.S >= 9)) {
+        const bool one = p.R * p.S == 1;
+        const bool glds = glds_env > 0 || (glds_env < 0 && (!one || (p.K >= 128 && p.C >= 128)));
+        const bool bk64 = glds && (bk_env == 64 || (bk_env == 0 && one));
+        if (bk64) {
+            if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true, true, 64>), grid, block, 0, stream, p);
+            else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true, true, 64>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false, true, 64>), grid, block, 0, stream, p);
+            return ddl_launch_status();
+        }
+        if (glds) {
             if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true, true>), grid, block, 0, stream, p);
             else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false, true>), grid, block, 0, stream, p);

@@ -296,15 +296,31 @@ def _conv_wgrad(dy, x, w, stride, padding):
             # raw event + raw stream handle: no torch stream context, no torch Event objects and a
             # persistent partial-sum workspace (side-stream kernels run in order, one buffer
             # serves them all) - ~25 us of host time per weight gradient less
-            raw = side.cuda_stream
-            K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
-            _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                        accumulate=True, stream=raw, workspace=_side_workspace)
-            # the caching allocator must not hand these blocks out again before the side stream
-            # is done with them
-            dy.record_stream(side)
-            x.record_stream(side)
+            if _SIDE_LEAN:
+                raw = side.cuda_stream
+                K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
+                _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
+                            accumulate=True, stream=raw, workspace=_side_workspace)
+            else:  # torch's own stream switch and events (DDL_SIDE_LEAN=0)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
+                                accumulate=True)
+            # The side stream reads dy and x after this function returns.  They are kept alive
+            # until the join at the end of backward instead of `record_stream`: blocks with a
+            # recorded stream are withheld from reuse until that stream has passed an event, and
+            # with the host several steps ahead of the GPU the allocator then keeps calling
+            # hipMalloc for new segments (reserved memory 27 -> 55-70 GB, and in 8 % of the bench
+            # processes a 1-1.8 s burst of device allocations inside the timed loop -
+            # profiles/r1_notes.md).  Released after the join is queued, they go back to this
+            # stream's pool and any later kernel that receives them is ordered after the side
+            # stream's reads.
             _side_mark_used()
+            if _SIDE["join_queued"]:
+                _SIDE["keep"].append((dy, x))
+            else:  # raw call outside a backward pass: nobody is known to join, let the allocator track it
+                dy.record_stream(side)
+                x.record_stream(side)
         _notify(w)
         return None
     return _wgrad_into(dy, x, _geom(x), torch.empty_like(w), Kc, R, S, stride, padding, padding,
@@ -312,7 +328,9 @@ def _conv_wgrad(dy, x, w, stride, padding):
 
 
 # ---- second stream for weight gradients --------------------------------------------------------
-_SIDE = {"on": True, "stream": None, "pending": False, "event": None, "ws": None}
+_SIDE = {"on": True, "stream": None, "pending": False, "event": None, "ws": None, "keep": [], "join_queued": False}
+import os as _os
+_SIDE_LEAN = _os.environ.get("DDL_SIDE_LEAN", "1") != "0"
 
 
 def _side_workspace(nbytes):
@@ -368,6 +386,9 @@ def _join_side_stream():
         if main is not None and main != cur:  # the stream backward ran on
             main.wait_stream(st)
     _SIDE["pending"] = False
+    _SIDE["join_queued"] = False
+    if _SIDE["keep"]:
+        _SIDE["keep"] = []   # operands of the queued weight gradients: free to be reused from here on
 
 
 def _side_mark_used():
@@ -378,8 +399,9 @@ def _side_mark_used():
         _SIDE["main"] = torch.cuda.current_stream()
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+            _SIDE["join_queued"] = True
         except RuntimeError:  # not inside a backward pass (raw calls in tests / benchmarks)
-            pass
+            _SIDE["join_queued"] = False
 
 
 class grad_exchange_context:
