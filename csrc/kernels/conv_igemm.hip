@@ -609,7 +609,7 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
     p.tiles_n = (N + 127) / 128;
     if (big) {
         p.tiles_m = (int)((M + 255) / 256);
-        return (deep && force_bk == 64) ? launch_cfg<256, 128, 64>(p, stream) : launch_cfg<256, 128, 32>(p, stream);
+        return launch_cfg<256, 128, 32>(p, stream);  // (a BK=64 twin needs 96 KB of LDS: one workgroup per CU, 15-30 % slower)
     }
     return deep ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
 }

@@ -87,3 +87,39 @@ def test_estimator_train_eval_predict_and_model_dir(tmp_path):
     est2.train(lambda: iter(data), steps=2)
     assert est2.global_step == 12
     assert before is None
+
+
+def test_graphed_train_step_runs_eagerly_without_a_gpu():
+    """training/graph.py on CPU tensors: never captures, behaves exactly like the plain loop
+    (zero_grad, forward, loss, backward, step) and returns a detached loss."""
+    import torch
+    from distributeddeeplearning_amd.training.graph import GraphedTrainStep
+
+    def make():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+        return m, torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(5, 8, generator=g) for _ in range(6)]
+    ts = [torch.randint(0, 4, (5,), generator=g) for _ in range(6)]
+    loss_fn = torch.nn.functional.cross_entropy
+    m1, o1 = make()
+    ref = []
+    for x, t in zip(xs, ts):
+        o1.zero_grad()
+        loss = loss_fn(m1(x), t)
+        loss.backward()
+        o1.step()
+        ref.append(float(loss))
+    m2, o2 = make()
+    step = GraphedTrainStep(m2, o2, loss_fn, warmup=2)
+    got = []
+    for x, t in zip(xs, ts):
+        out = step(x, t)
+        assert not out.requires_grad
+        got.append(float(out))
+    assert not step.graphed and step.failed is None
+    assert got == ref
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
