@@ -350,7 +350,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     // and only then consumed.  (One branchy row at a time made hipcc emit `s_waitcnt vmcnt(0)`
     // after every load: 2-3 exposed memory round trips per row, 3.3 TB/s on the layer-1 EPI-4
     // kernel against 4.5 TB/s for a plain streaming kernel — profiles/r1_notes.md.)
-    constexpr int BATCH = OITER < 4 ? OITER : 4;
+#ifndef DDL_EPI_BATCH
+#define DDL_EPI_BATCH 4   // rows per thread whose epilogue reads are in flight together (8 measured: profiles/r1_notes.md)
+#endif
+    constexpr int BATCH = OITER < DDL_EPI_BATCH ? OITER : DDL_EPI_BATCH;
     const bool col_ok = n < p.N;
     constexpr int SUB = BM / 128, SUB_ITERS = OITER / SUB;  // a thread's rows of one 128-row sub-tile are consecutive iterations
     static_assert(SUB_ITERS % BATCH == 0, "a batch never straddles two sub-tiles");

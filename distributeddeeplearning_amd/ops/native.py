@@ -24,7 +24,8 @@ _PKG = os.path.dirname(_HERE)
 _lock = threading.Lock()
 _cache: dict[str, object] = {}
 
-KERNELS_SO = os.path.join(_PKG, "_ddl_kernels.so")
+# DDL_KERNELS_SO: A/B a differently built kernel library (e.g. `hipcc -DDDL_EPI_BATCH=8 ...`) in one GPU session
+KERNELS_SO = os.environ.get("DDL_KERNELS_SO") or os.path.join(_PKG, "_ddl_kernels.so")
 ENGINE_SO = os.path.join(_PKG, "_ddl_engine.so")
 
 
