@@ -605,7 +605,8 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
     if (force_bk == 32) deep = false;
     if (force_bk == 64) deep = true;
     if (C % 64) deep = false;
-    if (N <= 64) {
+    static const int force_bn = getenv("DDL_CONV_BN") ? atoi(getenv("DDL_CONV_BN")) : 0;  // tuning knob (64: narrow tiles everywhere)
+    if (N <= 64 || force_bn == 64) {
         p.tiles_n = (N + 63) / 64;
         return deep ? launch_cfg<128, 64, 64>(p, stream) : launch_cfg<128, 64, 32>(p, stream);
     }
