@@ -608,6 +608,7 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
     static const int force_bn = getenv("DDL_CONV_BN") ? atoi(getenv("DDL_CONV_BN")) : 0;  // tuning knob (64: narrow tiles everywhere)
     if (N <= 64 || force_bn == 64) {
         p.tiles_n = (N + 63) / 64;
+        // (a 256x64 tile measured 5-12 % slower than 128x64 on the N = 64 layers: profiles/r1_notes.md)
         return deep ? launch_cfg<128, 64, 64>(p, stream) : launch_cfg<128, 64, 32>(p, stream);
     }
     p.tiles_n = (N + 127) / 128;
