@@ -127,6 +127,17 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
                 kwargs = {}
                 if want == "rccl":
                     kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
+                    # Collectives on a HIGH-priority stream: besides pre-empting compute at
+                    # workgroup dispatch, a priority class of its own gives the stream a hardware
+                    # queue of its own.  A normal-priority pool stream shared queue 4 with the
+                    # compute stream (rocprofv3 trace, profiles/r1_notes.md): the collective's
+                    # wait for the weight-gradient stream then sat in front of the compute
+                    # stream's packets and stalled it 100-150 us per bucket.
+                    if cfg.high_priority_comm and hasattr(dist, "ProcessGroupNCCL"):
+                        try:
+                            kwargs["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                        except Exception:  # pragma: no cover - older torch
+                            pass
                 dist.init_process_group(backend="nccl" if want == "rccl" else "gloo",
                                         init_method="env://", rank=rk, world_size=world,
                                         timeout=tmo, **kwargs)

@@ -173,6 +173,7 @@ class EngineConfig:
     cycle_time_ms: float = 0.0  # accepted for Horovod compat; static buckets need no cycle
     # run the gradient exchange even with one rank (rehearses the RCCL path on a one-GPU box)
     force_collectives: bool = False
+    high_priority_comm: bool = True   # RCCL collectives on a high-priority HIP stream (own hardware queue)
 
     @classmethod
     def from_env(cls) -> "EngineConfig":
@@ -192,4 +193,5 @@ class EngineConfig:
             fault_inject=env_str("HVD_FAULT_INJECT", None),
             cycle_time_ms=env_float("HVD_CYCLE_TIME", 0.0, "HOROVOD_CYCLE_TIME"),
             force_collectives=env_bool("HVD_FORCE_COLLECTIVES", False),
+            high_priority_comm=env_bool("HVD_HIGH_PRIORITY_COMM", True),
         )
