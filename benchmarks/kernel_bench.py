@@ -144,6 +144,18 @@ def main():
             tot["blaslt"] = tot.get("blaslt", 0.0) + tl * count
             tot["fwd_1x1s1"] = tot.get("fwd_1x1s1", 0.0) + tf_ * count
             line += " | hipBLASLt gemm %7.1f us %5.0f TF/s" % (tl * 1e3, flops / tl / 1e9)
+            # the weight gradient of a 1x1 conv as a plain library GEMM: dW[K, C] = dY^T[K, M] . X[M, C]
+            dy2 = dy.permute(0, 2, 3, 1).reshape(M, cout)
+            ow = torch.empty((cout, cin), dtype=bf, device=dev)
+
+            def ltw():
+                torch.matmul(dy2.t(), x2, out=ow)
+
+            tlw = timeit(ltw, args.iters)
+            row["blaslt_wgrad_us"] = tlw * 1e3
+            tot["blaslt_wgrad"] = tot.get("blaslt_wgrad", 0.0) + tlw * count
+            tot["wgrad_1x1s1"] = tot.get("wgrad_1x1s1", 0.0) + tw * count
+            line += " | wgrad gemm %7.1f us" % (tlw * 1e3)
         print(line, flush=True)
         rows.append(row)
         del x, w, y, dy, dx, stats
