@@ -21,9 +21,16 @@ def _launch(scenario, np_total=2, exports=None, timeout=240):
     sink = io.StringIO()
     env = {"HVD_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}
     env.update(exports or {})
-    rc = ddlrun.launch([sys.executable, "-u", WORKER, scenario], np_total,
-                       hosts=[("localhost", np_total)], exports=env, timeout=timeout, sink=sink)
-    out = sink.getvalue()
+    for attempt in range(2):
+        rc = ddlrun.launch([sys.executable, "-u", WORKER, scenario], np_total,
+                           hosts=[("localhost", np_total)], exports=env, timeout=timeout, sink=sink)
+        out = sink.getvalue()
+        # the launcher's free-port probe and the rendezvous bind are two steps: another process
+        # on the machine can take the port in between (seen once in ~150 suite runs)
+        if rc == 0 or attempt or not any(s in out for s in ("Address already in use", "EADDRINUSE")):
+            break
+        sink.seek(0)
+        sink.truncate()
     results = {}
     for line in out.splitlines():
         if "RESULT " in line:
