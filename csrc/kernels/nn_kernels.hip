@@ -67,37 +67,52 @@ __global__ void __launch_bounds__(256) bn_stats_partial_kernel(const bf16_t* __r
 // stage 2 (one thread per channel) folds the P slices, updates the running statistics (unbiased
 // variance, like torch) and emits the fused scale/shift of K7.
 // ---------------------------------------------------------------------------------------------
+// Fold tiles t0+ty, t0+ty+16, ... < t1 of channel c: eight tiles (16 loads) in flight per round.
+// These kernels sit on dependent chains (conv -> fold -> finalize -> apply) and their run time
+// is load latency, which under a busy weight-gradient stream is several microseconds a round.
+template <typename Acc>
+__device__ __forceinline__ void bn_fold_lane16(const float* __restrict__ partial, int t0, int t1, int C, int c, int ty,
+                                               Acc& s1, Acc& s2) {
+    int t = t0 + ty;
+    for (; t + 112 < t1; t += 128) {
+        float a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[j] = partial[((long long)(t + 16 * j) * 2) * C + c];
+            b[j] = partial[((long long)(t + 16 * j) * 2 + 1) * C + c];
+        }
+        s1 += (((Acc)a[0] + (Acc)a[1]) + ((Acc)a[2] + (Acc)a[3])) + (((Acc)a[4] + (Acc)a[5]) + ((Acc)a[6] + (Acc)a[7]));
+        s2 += (((Acc)b[0] + (Acc)b[1]) + ((Acc)b[2] + (Acc)b[3])) + (((Acc)b[4] + (Acc)b[5]) + ((Acc)b[6] + (Acc)b[7]));
+    }
+    for (; t + 16 < t1; t += 32) {
+        float a0 = partial[((long long)t * 2) * C + c], b0 = partial[((long long)t * 2 + 1) * C + c];
+        float a1 = partial[((long long)(t + 16) * 2) * C + c], b1 = partial[((long long)(t + 16) * 2 + 1) * C + c];
+        s1 += (Acc)a0 + (Acc)a1;
+        s2 += (Acc)b0 + (Acc)b1;
+    }
+    if (t < t1) {
+        s1 += (Acc)partial[((long long)t * 2) * C + c];
+        s2 += (Acc)partial[((long long)t * 2 + 1) * C + c];
+    }
+}
+
+// grid (C/16, P), 256 threads = 16 channels x 16 tile lanes
 template <typename OutT>
 __global__ void __launch_bounds__(256) bn_stats_fold_kernel(const float* __restrict__ partial, int T, int C, int P,
                                                            OutT* __restrict__ folded /*[P][2][C]*/) {
-    __shared__ double r1[4][64], r2[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    __shared__ double r1[16][16], r2[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
     const int per = (T + P - 1) / P;
     const int t0 = blockIdx.y * per;
     int t1 = t0 + per;
     if (t1 > T) t1 = T;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        int t = t0 + ty;
-        for (; t + 12 < t1; t += 16) {
-            float a0 = partial[((long long)t * 2) * C + c], b0 = partial[((long long)t * 2 + 1) * C + c];
-            float a1 = partial[((long long)(t + 4) * 2) * C + c], b1 = partial[((long long)(t + 4) * 2 + 1) * C + c];
-            float a2 = partial[((long long)(t + 8) * 2) * C + c], b2 = partial[((long long)(t + 8) * 2 + 1) * C + c];
-            float a3 = partial[((long long)(t + 12) * 2) * C + c], b3 = partial[((long long)(t + 12) * 2 + 1) * C + c];
-            s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-            s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
-        }
-        for (; t < t1; t += 4) {
-            s1 += (double)partial[((long long)t * 2) * C + c];
-            s2 += (double)partial[((long long)t * 2 + 1) * C + c];
-        }
-    }
+    if (c < C) bn_fold_lane16<double>(partial, t0, t1, C, c, ty, s1, s2);
     r1[ty][tx] = s1; r2[ty][tx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
-        s1 = (r1[0][tx] + r1[1][tx]) + (r1[2][tx] + r1[3][tx]);
-        s2 = (r2[0][tx] + r2[1][tx]) + (r2[2][tx] + r2[3][tx]);
+        for (int l = 1; l < 16; ++l) { s1 += r1[l][tx]; s2 += r2[l][tx]; }
         folded[((long long)blockIdx.y * 2) * C + c] = (OutT)s1;
         folded[((long long)blockIdx.y * 2 + 1) * C + c] = (OutT)s2;
     }
@@ -276,30 +291,19 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
 
 // K8b: dgamma = invstd*(s2 - mean*s1), dbeta = s1, and the per-channel coefficients of
 // dy = ca*g + cb*y + cc  (ca = gamma*invstd, cb = -ca*invstd*dgamma/M, cc = -ca*s1/M - cb*mean)
-__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, int C, long long M,
-                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                              const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/, int accumulate) {
-    __shared__ float a1[16][64], a2[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+// 16 channels x 16 tile lanes per block of 256 threads (2 KB of LDS): the kernel sits on the
+// dependent chain dgrad -> finalize -> apply while the weight-gradient stream keeps the CUs full,
+// and a 1024-thread block with 8 KB of LDS waited 10-60 us for a CU that could hold it
+// (kernel trace, profiles/r1_notes.md); small blocks slip into the holes.
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, int G, int C, long long M,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ coef /*[3][C]*/, int accumulate) {
+    __shared__ float a1[16][16], a2[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
     float s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-        float p1 = 0.f, p2 = 0.f, q1 = 0.f, q2 = 0.f, r1 = 0.f, r2 = 0.f;
-        int t = ty;
-        for (; t + 48 < G; t += 64) {  // four independent chains per lane
-            s1 += partial[((long long)t * 2) * C + c];          s2 += partial[((long long)t * 2 + 1) * C + c];
-            p1 += partial[((long long)(t + 16) * 2) * C + c];   p2 += partial[((long long)(t + 16) * 2 + 1) * C + c];
-            q1 += partial[((long long)(t + 32) * 2) * C + c];   q2 += partial[((long long)(t + 32) * 2 + 1) * C + c];
-            r1 += partial[((long long)(t + 48) * 2) * C + c];   r2 += partial[((long long)(t + 48) * 2 + 1) * C + c];
-        }
-        for (; t < G; t += 16) {
-            s1 += partial[((long long)t * 2) * C + c];
-            s2 += partial[((long long)t * 2 + 1) * C + c];
-        }
-        s1 = (s1 + p1) + (q1 + r1);
-        s2 = (s2 + p2) + (q2 + r2);
-    }
+    if (c < C) bn_fold_lane16<float>(partial, 0, G, C, c, ty, s1, s2);
     a1[ty][tx] = s1; a2[ty][tx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
@@ -773,7 +777,7 @@ extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long 
         return ddl_launch_status();
     }
     const int P = (int)ddl_bn_fold_slices(T);
-    hipLaunchKernelGGL(bn_stats_fold_kernel<double>, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
+    hipLaunchKernelGGL(bn_stats_fold_kernel<double>, dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
                        (double*)workspace);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)workspace, P, C, M,
                        (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
@@ -845,13 +849,13 @@ extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long 
     CHK(partial && gamma && mean && invstd && dgamma && dbeta && coef && G > 0 && C > 0 && M > 0, DDL_EINVAL);
     if (workspace && G > 512) {
         const int P = (int)ddl_bn_fold_slices(G);
-        hipLaunchKernelGGL(bn_stats_fold_kernel<float>, dim3((C + 63) / 64, P), dim3(256), 0, stream, (const float*)partial, G, C,
+        hipLaunchKernelGGL(bn_stats_fold_kernel<float>, dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial, G, C,
                            P, (float*)workspace);
         if (ddl_launch_status() != DDL_OK) return DDL_ELAUNCH;
         partial = workspace;
         G = P;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, G, C, M,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)partial, G, C, M,
                        (const float*)gamma, (const float*)mean, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef, accumulate);
     return ddl_launch_status();
 }
