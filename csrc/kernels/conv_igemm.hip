@@ -49,6 +49,10 @@ struct IGemmParams {
     const bf16_t* ep_y;      // EPI 2: pre-BatchNorm activation of the layer whose output gradient this is
     const float* ep_fcoef;   // EPI 2: [2][N] forward scale | shift of that BatchNorm (ReLU mask = scale*y+shift > 0)
     const bf16_t* ep_mask;   // EPI 3: ReLU output; the result is zeroed where it is <= 0
+    // EPI 4, optional: a second pre-BatchNorm tensor fed by the same gradient (the projection
+    // shortcut's conv output); `stats2` receives [stat_rows][2][N] = sum g | sum g*ep_y2
+    const bf16_t* ep_y2;
+    float* stats2;
 };
 
 // byte offset of 16-byte chunk `ch` of row `row` in a [rows][BK] bf16 LDS tile (swizzled)
@@ -63,7 +67,8 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 //        tile's sum g / sum g*y partials are emitted (replaces the separate K8a reduce pass);
 //      3 backward-data whose consumer is a ReLU: store dz * (mask > 0) so that the consumer's
 //        backward needs neither the mask tensor nor a masked copy of the gradient;
-//      4 = 3 plus the sum g / sum g*y partials of the BatchNorm that feeds that ReLU (ep_y).
+//      4 = 3 plus the sum g / sum g*y partials of the BatchNorm that feeds that ReLU (ep_y), and
+//        with ep_y2 also those of the projection shortcut's BatchNorm (same g, other y).
 template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p) {
     static_assert(BM % 128 == 0, "statistics rows are per 128 output rows");
@@ -76,7 +81,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     constexpr int WM = BM / 2, WN = BN / 2;  // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int OSTR = BN * 2 + 16;        // padded out-tile row stride (bytes)
-    constexpr int EPI_BYTES = BM * OSTR + 8 * BN * 4;  // out tile + [4 waves][2][BN] fp32 stats scratch
+    constexpr int SROWS = EPI == 4 ? 3 : 2;   // sums per channel kept by the epilogue
+    constexpr int EPI_BYTES = BM * OSTR + 4 * SROWS * BN * 4;  // out tile + [4 waves][SROWS][BN] fp32 stats scratch
     constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -341,9 +347,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     constexpr int OCPR = BN / 8, ORPP = 256 / OCPR, OITER = BM / ORPP;
     const int oc = tid % OCPR, orow0 = tid / OCPR;
     const int n = n0 + oc * 8;
-    float s1[8], s2[8], fsc[8], fsh[8];
+    float s1[8], s2[8], s3[8], fsc[8], fsh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; fsc[e] = 0.f; fsh[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; fsc[e] = 0.f; fsh[e] = 0.f; }
+    const bool y2on = EPI == 4 && p.ep_y2 != nullptr;  // uniform
     if (EPI == 2 && n < p.N) { load8f(p.ep_fcoef + n, fsc); load8f(p.ep_fcoef + p.N + n, fsh); }
     // Rows are handled in batches: all global reads of a batch (shortcut gradient, ReLU mask, BN
     // input) are issued back to back with clamped addresses — no branch and no wait between them —
@@ -359,30 +366,39 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
     static_assert(SUB_ITERS % BATCH == 0, "a batch never straddles two sub-tiles");
     auto emit_stats = [&](int sub) {
         // lanes with equal (tid % OCPR) hold the same channels: fold the wave, then the 4 waves
-        float* red = reinterpret_cast<float*>(smem + BM * OSTR);  // [4 waves][2][BN]
+        float* red = reinterpret_cast<float*>(smem + BM * OSTR);  // [4 waves][SROWS][BN]
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
             for (int o = OCPR; o < 64; o <<= 1) {
                 s1[e] += __shfl_xor(s1[e], o, 64);
                 s2[e] += __shfl_xor(s2[e], o, 64);
+                if (EPI == 4) s3[e] += __shfl_xor(s3[e], o, 64);
             }
         }
         if (sub > 0) __syncthreads();  // the previous sub-tile's fold has been read
-        float* r1 = red + wid * 2 * BN;
+        float* r1 = red + wid * SROWS * BN;
         if (lane < OCPR) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { r1[lane * 8 + e] = s1[e]; r1[BN + lane * 8 + e] = s2[e]; }
+            for (int e = 0; e < 8; ++e) {
+                r1[lane * 8 + e] = s1[e]; r1[BN + lane * 8 + e] = s2[e];
+                if (EPI == 4) r1[2 * BN + lane * 8 + e] = s3[e];
+            }
         }
         __syncthreads();
         const int srow = tile_m * SUB + sub;
         if (tid < 2 * BN && srow < p.stat_rows) {
-            float t = red[tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
+            float t = red[tid] + red[SROWS * BN + tid] + red[2 * SROWS * BN + tid] + red[3 * SROWS * BN + tid];
             int which = tid / BN, c = tid - which * BN;
             if (n0 + c < p.N) p.stats[((long long)srow * 2 + which) * p.N + n0 + c] = t;
+            if (y2on && n0 + c < p.N) {  // second table: row 0 = the same sum g, row 1 = sum g*y2
+                int src = which ? 2 * BN + c : c;
+                float u = red[src] + red[SROWS * BN + src] + red[2 * SROWS * BN + src] + red[3 * SROWS * BN + src];
+                p.stats2[((long long)srow * 2 + which) * p.N + n0 + c] = u;
+            }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; }
     };
 #pragma unroll
     for (int it0 = 0; it0 < OITER; it0 += BATCH) {
@@ -413,7 +429,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
                 has[b] = h; aoff[b] = h ? ao : 0;
             }
         }
-        bf16x8 av[BATCH], zm[BATCH], yv[BATCH];
+        bf16x8 av[BATCH], zm[BATCH], yv[BATCH], y2v[BATCH];
         if (ADDEND) {
 #pragma unroll
             for (int b = 0; b < BATCH; ++b) av[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.addend + aoff[b]));
@@ -425,6 +441,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
         if (EPI == 2 || EPI == 4) {
 #pragma unroll
             for (int b = 0; b < BATCH; ++b) yv[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_y + off[b]));
+        }
+        if (y2on) {
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) y2v[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_y2 + off[b]));
         }
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
@@ -442,6 +462,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
             if (EPI == 4) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float g = bf2f(v[e]) * live; s1[e] += g; s2[e] += g * bf2f(yv[b][e]); }
+                if (y2on) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s3[e] += bf2f(v[e]) * live * bf2f(y2v[b][e]);
+                }
             }
             if (EPI == 2) {
 #pragma unroll
@@ -524,12 +548,12 @@ extern "C" int ddl_conv_igemm_tiles_m_bwd(long long M, int Hout, int Wout, int i
     return (int)((M + 127) / 128);
 }
 
-extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const void* addend, void* stats,
-                                 long long x_numel, long long w_numel,
-                                 int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
-                                 int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
-                                 int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
-                                 hipStream_t stream) {
+extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const void* addend, void* stats,
+                                  long long x_numel, long long w_numel,
+                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                  int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
+                                  int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
+                                  const void* ep_y2, void* stats2, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || N <= 0 || R <= 0 || S <= 0) return DDL_EINVAL;
     if (C % 32 != 0 || N % 8 != 0) return DDL_EINVAL;
     if (idil != 1 && idil != 2 && idil != 4) return DDL_EINVAL;
@@ -543,6 +567,8 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
     if (ep_fcoef && (!ep_y || ep_mask || addend)) return DDL_EINVAL;
     if (ep_y && (!stats || (ep_fcoef == nullptr) == (ep_mask == nullptr))) return DDL_EINVAL;
     if (ep_mask && stats && !ep_y) return DDL_EINVAL;
+    // second BatchNorm of the same gradient: EPI 4 only, with a table of its own
+    if ((ep_y2 == nullptr) != (stats2 == nullptr) || (ep_y2 && !(ep_y && ep_mask)) || (ep_y2 && !ddl_aligned16(ep_y2))) return DDL_EINVAL;
     if ((xs_b % 8) || (xs_h % 8)) return DDL_EALIGN;
     // every tap address must be 16-byte aligned: either pixels are >= 8 elements apart, or (S == 1,
     // undilated) only multiples of ostride are visited and those are
@@ -558,6 +584,7 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
     p.addend = (const bf16_t*)addend; p.stats = (float*)stats;
     p.ep_y = (const bf16_t*)ep_y; p.ep_fcoef = (const float*)ep_fcoef; p.ep_mask = (const bf16_t*)ep_mask;
+    p.ep_y2 = (const bf16_t*)ep_y2; p.stats2 = (float*)stats2;
     p.x_bytes = (unsigned)(x_numel * 2); p.w_bytes = (unsigned)(w_numel * 2);
     // timing-only probe (results are wrong): a descriptor with zero records drops every load through
     // it while the instruction stream, waits and barriers stay - prices one operand's traffic
@@ -617,6 +644,17 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
         return launch_cfg<256, 128, 32>(p, stream);  // (a BK=64 twin needs 96 KB of LDS: one workgroup per CU, 15-30 % slower)
     }
     return deep ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
+}
+
+extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const void* addend, void* stats,
+                                 long long x_numel, long long w_numel,
+                                 int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                 int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
+                                 int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
+                                 hipStream_t stream) {
+    return ddl_conv_igemm_ex2(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
+                              N, R, S, ostride, pad, pad_w, idil, addend_sub2, ep_y, ep_fcoef, ep_mask, nullptr, nullptr,
+                              stream);
 }
 
 extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void* addend, void* stats,

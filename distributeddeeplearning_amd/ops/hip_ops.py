@@ -226,11 +226,13 @@ def _conv_fwd(x, w, stride, padding, want_stats):
 
 
 def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False, mask_src=None,
-                bn_y=None):
+                bn_y=None, bn_y2=None):
     """dx of a convolution; ``addend`` is summed in the epilogue (shortcut gradient) and
     ``mask_src`` (the ReLU output that IS the conv input) zeroes dx where it is <= 0.  With
     ``bn_y`` (the pre-BatchNorm tensor behind that ReLU; needs ``mask_src``) the kernel also
-    emits that BatchNorm's backward partial sums and ``(dx, partial)`` is returned."""
+    emits that BatchNorm's backward partial sums and ``(dx, partial)`` is returned; ``bn_y2``
+    (a second BatchNorm input fed by the same gradient: the projection shortcut's conv output)
+    adds a table of its own: ``(dx, partial, partial2)``."""
     B, C, H, W = x_shape
     _, _, R, S = w.shape
     wt = _WT.get(w)
@@ -242,14 +244,18 @@ def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False,
         dx[:, :, ::2, ::2] = _conv_dgrad_1x1s2_compact(dy, w)
         return dx
     dx = _empty_nhwc(B, C, H, W, dy.device)
-    partial = None
+    partial = partial2 = None
     if bn_y is not None:
         T = K.conv_tiles_m_bwd(B * H * W, H, W, stride, 1)
         partial = torch.empty((T, 2, C), dtype=torch.float32, device=dy.device)
+        if bn_y2 is not None:
+            partial2 = torch.empty((T, 2, C), dtype=torch.float32, device=dy.device)
     K.conv_igemm(dy, _geom(dy), wt, dx, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
                  addend=addend, addend_sub2=addend_sub2, ep_mask=mask_src, ep_y=bn_y,
-                 stats=partial)
-    return dx if bn_y is None else (dx, partial)
+                 stats=partial, ep_y2=bn_y2 if bn_y is not None else None, stats2=partial2)
+    if bn_y is None:
+        return dx
+    return (dx, partial) if bn_y2 is None else (dx, partial, partial2)
 
 
 def _conv_dgrad_bn(dy, w, x_shape, stride, padding, y_prev, fcoef_prev):
@@ -872,6 +878,7 @@ class ResidualBlockFn(Function):
             cur = z
         if len(cfg) > 11 and cfg[11] is not None:
             cfg[11].y = saved_y[-1]
+            cfg[11].y2 = yd if (has_ds and training) else None
         ctx.cfg = cfg
         ctx.n_in = 2 + len(tensors)
         ctx.params = groups  # parameters/buffers are leaves: plain references are safe
@@ -917,9 +924,10 @@ class ResidualBlockFn(Function):
         g_short = None
         # BatchNorm-backward partials produced by the previous dgrad's epilogue (for the last
         # unit: by the NEXT block's input-gradient kernel, handed over through the chain link)
-        fused = None
+        fused = fused_ds = None
         if grad_premasked and link_out is not None:
             fused, link_out.partial = link_out.partial, None
+            fused_ds, link_out.partial2 = link_out.partial2, None
         for i in range(units - 1, -1, -1):
             w, gam, bet = groups[i][0], groups[i][1], groups[i][2]
             last = i == units - 1
@@ -945,7 +953,8 @@ class ResidualBlockFn(Function):
                 if has_ds:
                     wd, gd, bd = groups[units][0], groups[units][1], groups[units][2]
                     yd, cd = saved[1 + 3 * units], saved[2 + 3 * units]
-                    dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False)
+                    dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False,
+                                                 partial=fused_ds)
                     dwd = _conv_wgrad(dyd, x, wd, ds_stride, 0)
                     put(units, dwd, dgd, dbd)
                     if ctx.needs_input_grad[0]:
@@ -958,10 +967,15 @@ class ResidualBlockFn(Function):
                                          _FUSE_BN_REDUCE["on"]) else None
                     if bn_y is not None and bn_y.shape != x.shape:
                         bn_y = None
+                    bn_y2 = link_in.y2 if (bn_y is not None and _FUSE_DS_REDUCE["on"]) else None
+                    if bn_y2 is not None and bn_y2.shape != x.shape:
+                        bn_y2 = None
                     res = _conv_dgrad(dy, w, x.shape, strides[i], pads[i], addend=addend,
                                       addend_sub2=sub2, mask_src=x if premask_in else None,
-                                      bn_y=bn_y)
-                    if bn_y is not None:
+                                      bn_y=bn_y, bn_y2=bn_y2)
+                    if bn_y2 is not None:
+                        grads[0], link_in.partial, link_in.partial2 = res
+                    elif bn_y is not None:
                         grads[0], link_in.partial = res
                     else:
                         grads[0] = res
@@ -974,6 +988,9 @@ def residual_block_supported(convs):
 
 
 _FUSE_BN_REDUCE = {"on": True}
+# the projection shortcut's BatchNorm partials ride in the same epilogue (DDL_FUSE_DS_REDUCE=0:
+# separate reduce pass over the block's output gradient, the A/B switch)
+_FUSE_DS_REDUCE = {"on": _os.environ.get("DDL_FUSE_DS_REDUCE", "1") != "0"}
 
 
 class _ChainLink:
@@ -981,11 +998,13 @@ class _ChainLink:
     pre-BatchNorm output of its last unit (``y``) for the later block, whose backward returns
     the BatchNorm-backward partial sums (``partial``) computed in its input-gradient epilogue."""
 
-    __slots__ = ("y", "partial")
+    __slots__ = ("y", "partial", "y2", "partial2")
 
     def __init__(self):
         self.y = None
         self.partial = None
+        self.y2 = None          # the earlier block's projection-shortcut conv output, if it has one
+        self.partial2 = None    # ... and the partials of that BatchNorm (same gradient, other input)
 
 
 def residual_block(x, units, downsample, training, momentum, eps, premask_in=False,

@@ -224,14 +224,16 @@ def storage_numel_from(x):
 
 
 def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil, Hout, Wout,
-               addend=None, stats=None, addend_sub2=False, ep_y=None, ep_fcoef=None, ep_mask=None):
+               addend=None, stats=None, addend_sub2=False, ep_y=None, ep_fcoef=None, ep_mask=None,
+               ep_y2=None, stats2=None):
     """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel).
 
     Fused backward epilogues: ``ep_y`` + ``ep_fcoef`` (+ ``stats``) store the gradient masked by
     the ReLU of ``bn(ep_y)`` and emit the BatchNorm-backward partial sums per tile; ``ep_mask``
-    zeroes the result where that tensor is <= 0."""
+    zeroes the result where that tensor is <= 0; ``ep_y2`` + ``stats2`` (with ``ep_y`` and
+    ``ep_mask``): partial sums of a second BatchNorm fed by the same gradient."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
-    for t in (ep_y, ep_mask):
+    for t in (ep_y, ep_mask, ep_y2):
         if t is not None and t.numel() != y.numel():
             raise KernelError("conv_igemm: epilogue tensor does not match the output shape")
     if ep_fcoef is not None and ep_fcoef.__class__ is not int and \
@@ -241,10 +243,13 @@ def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil,
         need = conv_tiles_m_bwd(y.numel() // n_out, Hout, Wout, idil, ostride) * 2 * n_out
         if stats is None or stats.numel() < need:
             raise KernelError("conv_igemm: partial buffer too small for the fused reduce")
-    f = _fn("ddl_conv_igemm_ex", "ppppp qq iiii qqq iiiiiiiiii pppp")
+    if ep_y2 is not None and (stats2 is None or stats is None or stats2.numel() < stats.numel()):
+        raise KernelError("conv_igemm: second partial buffer missing or too small")
+    f = _fn("ddl_conv_igemm_ex2", "ppppp qq iiii qqq iiiiiiiiii pppppp")
     check(f(x_ptr_tensor.data_ptr(), _p(w), y.data_ptr(), _p(addend), _p(stats), xn,
             w.numel(), B, Hin, Win, C, sb, sh, sw, Hout, Wout, n_out, R, S, ostride, pad, pad_w, idil,
-            1 if addend_sub2 else 0, _p(ep_y), _p(ep_fcoef), _p(ep_mask), _raw_stream()),
+            1 if addend_sub2 else 0, _p(ep_y), _p(ep_fcoef), _p(ep_mask), _p(ep_y2), _p(stats2),
+            _raw_stream()),
           "conv_igemm")
 
 

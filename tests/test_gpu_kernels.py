@@ -322,6 +322,15 @@ def test_dgrad_fused_bn_reduce_and_relu_mask_epilogues(case):
         ps = part.sum(0)
         assert torch.allclose(ps[0], t1, rtol=1e-3, atol=1e-3 * float(t1.abs().max()))
         assert torch.allclose(ps[1], t2, rtol=1e-3, atol=1e-3 * float(t2.abs().max()))
+        # a second BatchNorm fed by the same gradient (projection shortcut): its own table
+        y2 = rand_nhwc(B, Cin, H, W, seed=35)
+        both2, part_a, part_b = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad, addend=addend,
+                                                mask_src=z, bn_y=yprev, bn_y2=y2)
+        assert torch.equal(both2, masked) and torch.equal(part_a, part)
+        t3 = (masked.float() * y2.float()).sum(dim=(0, 2, 3))
+        pb = part_b.sum(0)
+        assert torch.equal(part_b[:, 0], part[:, 0])
+        assert torch.allclose(pb[1], t3, rtol=1e-3, atol=1e-3 * float(t3.abs().max()))
 
 
 def test_residual_chain_matches_unchained_blocks():
