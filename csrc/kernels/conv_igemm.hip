@@ -53,6 +53,9 @@ struct IGemmParams {
     // shortcut's conv output); `stats2` receives [stat_rows][2][N] = sum g | sum g*ep_y2
     const bf16_t* ep_y2;
     float* stats2;
+    // EPI 3 / 4: the ReLU mask as one bit per element (byte i = elements 8i .. 8i+7 of the [M][N]
+    // tensor, written by the forward BatchNorm apply) instead of the activation itself
+    const unsigned char* ep_maskbits;
 };
 
 // byte offset of 16-byte chunk `ch` of row `row` in a [rows][BK] bf16 LDS tile (swizzled)
@@ -351,6 +354,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; fsc[e] = 0.f; fsh[e] = 0.f; }
     const bool y2on = EPI == 4 && p.ep_y2 != nullptr;  // uniform
+    const bool maskbits = (EPI == 3 || EPI == 4) && p.ep_maskbits != nullptr;  // uniform
     if (EPI == 2 && n < p.N) { load8f(p.ep_fcoef + n, fsc); load8f(p.ep_fcoef + p.N + n, fsh); }
     // Rows are handled in batches: all global reads of a batch (shortcut gradient, ReLU mask, BN
     // input) are issued back to back with clamped addresses — no branch and no wait between them —
@@ -434,9 +438,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
 #pragma unroll
             for (int b = 0; b < BATCH; ++b) av[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.addend + aoff[b]));
         }
+        unsigned zb[BATCH];
         if (EPI == 3 || EPI == 4) {
+            if (maskbits) {
 #pragma unroll
-            for (int b = 0; b < BATCH; ++b) zm[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_mask + off[b]));
+                for (int b = 0; b < BATCH; ++b) zb[b] = p.ep_maskbits[off[b] >> 3];
+            } else {
+#pragma unroll
+                for (int b = 0; b < BATCH; ++b) zm[b] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.ep_mask + off[b]));
+            }
         }
         if (EPI == 2 || EPI == 4) {
 #pragma unroll
@@ -456,7 +466,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p)
             }
             if (EPI == 3 || EPI == 4) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = bf2f(zm[b][e]) > 0.f ? v[e] : f2bf(0.f);
+                for (int e = 0; e < 8; ++e) {
+                    bool keep = maskbits ? ((zb[b] >> e) & 1u) != 0 : bf2f(zm[b][e]) > 0.f;
+                    v[e] = keep ? v[e] : f2bf(0.f);
+                }
             }
             const float live = ok[b] ? 1.f : 0.f;   // rows past the edge add nothing to the sums
             if (EPI == 4) {
@@ -505,13 +518,14 @@ template <int BM, int BN, int BK, bool GLDS>
 int launch_cfg2(const IGemmParams& p, hipStream_t stream) {
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     static const int extra_lds = getenv("DDL_CONV_EXTRA_LDS") ? atoi(getenv("DDL_CONV_EXTRA_LDS")) : 0;  // occupancy probe
-    if (p.stats && p.addend && !(p.ep_y && p.ep_mask)) return DDL_EINVAL;
+    const bool mask = p.ep_mask || p.ep_maskbits;
+    if (p.stats && p.addend && !(p.ep_y && mask)) return DDL_EINVAL;
 #define DDL_LAUNCH(E, A) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, E, A, GLDS>), grid, block, extra_lds, stream, p)
-    if (p.ep_y && p.ep_mask && p.addend) DDL_LAUNCH(4, true);
-    else if (p.ep_y && p.ep_mask) DDL_LAUNCH(4, false);
+    if (p.ep_y && mask && p.addend) DDL_LAUNCH(4, true);
+    else if (p.ep_y && mask) DDL_LAUNCH(4, false);
     else if (p.ep_y) DDL_LAUNCH(2, false);
-    else if (p.ep_mask && p.addend) DDL_LAUNCH(3, true);
-    else if (p.ep_mask) DDL_LAUNCH(3, false);
+    else if (mask && p.addend) DDL_LAUNCH(3, true);
+    else if (mask) DDL_LAUNCH(3, false);
     else if (p.stats) DDL_LAUNCH(1, false);
     else if (p.addend) DDL_LAUNCH(0, true);
     else DDL_LAUNCH(0, false);
@@ -553,7 +567,7 @@ extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const v
                                   int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
                                   int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
                                   int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
-                                  const void* ep_y2, void* stats2, hipStream_t stream) {
+                                  const void* ep_y2, void* stats2, const void* ep_maskbits, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || N <= 0 || R <= 0 || S <= 0) return DDL_EINVAL;
     if (C % 32 != 0 || N % 8 != 0) return DDL_EINVAL;
     if (idil != 1 && idil != 2 && idil != 4) return DDL_EINVAL;
@@ -564,11 +578,13 @@ extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const v
     if ((ep_y && !ddl_aligned16(ep_y)) || (ep_fcoef && !ddl_aligned16(ep_fcoef)) || (ep_mask && !ddl_aligned16(ep_mask))) return DDL_EALIGN;
     // fused BatchNorm-backward reduce needs y, the forward coefficients and the partial buffer together
     // (EPI 2: ep_y + ep_fcoef, no addend; EPI 4: ep_y + ep_mask, addend allowed)
-    if (ep_fcoef && (!ep_y || ep_mask || addend)) return DDL_EINVAL;
-    if (ep_y && (!stats || (ep_fcoef == nullptr) == (ep_mask == nullptr))) return DDL_EINVAL;
-    if (ep_mask && stats && !ep_y) return DDL_EINVAL;
+    if (ep_mask && ep_maskbits) return DDL_EINVAL;
+    const bool has_mask = ep_mask || ep_maskbits;
+    if (ep_fcoef && (!ep_y || has_mask || addend)) return DDL_EINVAL;
+    if (ep_y && (!stats || (ep_fcoef == nullptr) == !has_mask)) return DDL_EINVAL;
+    if (has_mask && stats && !ep_y) return DDL_EINVAL;
     // second BatchNorm of the same gradient: EPI 4 only, with a table of its own
-    if ((ep_y2 == nullptr) != (stats2 == nullptr) || (ep_y2 && !(ep_y && ep_mask)) || (ep_y2 && !ddl_aligned16(ep_y2))) return DDL_EINVAL;
+    if ((ep_y2 == nullptr) != (stats2 == nullptr) || (ep_y2 && !(ep_y && has_mask)) || (ep_y2 && !ddl_aligned16(ep_y2))) return DDL_EINVAL;
     if ((xs_b % 8) || (xs_h % 8)) return DDL_EALIGN;
     // every tap address must be 16-byte aligned: either pixels are >= 8 elements apart, or (S == 1,
     // undilated) only multiples of ostride are visited and those are
@@ -585,6 +601,7 @@ extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const v
     p.addend = (const bf16_t*)addend; p.stats = (float*)stats;
     p.ep_y = (const bf16_t*)ep_y; p.ep_fcoef = (const float*)ep_fcoef; p.ep_mask = (const bf16_t*)ep_mask;
     p.ep_y2 = (const bf16_t*)ep_y2; p.stats2 = (float*)stats2;
+    p.ep_maskbits = (const unsigned char*)ep_maskbits;
     p.x_bytes = (unsigned)(x_numel * 2); p.w_bytes = (unsigned)(w_numel * 2);
     // timing-only probe (results are wrong): a descriptor with zero records drops every load through
     // it while the instruction stream, waits and barriers stay - prices one operand's traffic
@@ -654,7 +671,7 @@ extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const vo
                                  hipStream_t stream) {
     return ddl_conv_igemm_ex2(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
                               N, R, S, ostride, pad, pad_w, idil, addend_sub2, ep_y, ep_fcoef, ep_mask, nullptr, nullptr,
-                              stream);
+                              nullptr, stream);
 }
 
 extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void* addend, void* stats,

@@ -220,7 +220,8 @@ template <bool RELU, int RES, bool NT>
 __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const bf16_t* __restrict__ res,
                                                           const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                          bf16_t* __restrict__ z, long long nchunks, int cchunks) {
+                                                          bf16_t* __restrict__ z, unsigned char* __restrict__ bits,
+                                                          long long nchunks, int cchunks) {
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
         int c = (int)(i % cchunks) * 8;
@@ -240,6 +241,12 @@ __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restr
             o[e] = f2bf(f);
         }
         st8<NT>(z + (i << 3), o);
+        if (bits) {  // ReLU mask of this chunk, one bit per element, for the backward epilogues
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m |= (bf2f(o[e]) > 0.f ? 1u : 0u) << e;
+            bits[i] = (unsigned char)m;
+        }
     }
 }
 
@@ -793,9 +800,9 @@ extern "C" int ddl_bn_eval_coeffs(const void* gamma, const void* beta, const voi
     return ddl_launch_status();
 }
 
-extern "C" int ddl_bn_apply_fwd_ex(const void* y, const void* scale, const void* shift, const void* res,
-                                   const void* rscale, const void* rshift, void* z,
-                                   long long M, int C, int relu, hipStream_t stream) {
+extern "C" int ddl_bn_apply_fwd_ex2(const void* y, const void* scale, const void* shift, const void* res,
+                                    const void* rscale, const void* rshift, void* z, void* bits,
+                                    long long M, int C, int relu, hipStream_t stream) {
     CHK(y && scale && shift && z && M > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
     CHK((rscale == nullptr) == (rshift == nullptr) && (!rscale || res), DDL_EINVAL);
     CHK(ddl_aligned16(y) && ddl_aligned16(z) && ddl_aligned16(scale) && ddl_aligned16(shift) && (!res || ddl_aligned16(res)), DDL_EALIGN);
@@ -804,7 +811,7 @@ extern "C" int ddl_bn_apply_fwd_ex(const void* y, const void* scale, const void*
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
     const bool nt = M * C * 2 >= nt_threshold_bytes();
     const int rmode = !res ? 0 : (rscale ? 2 : 1);
-#define L2(R, S, N) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S, N>), grid, block, 0, stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (const float*)rscale, (const float*)rshift, (bf16_t*)z, nchunks, C >> 3)
+#define L2(R, S, N) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S, N>), grid, block, 0, stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (const float*)rscale, (const float*)rshift, (bf16_t*)z, (unsigned char*)bits, nchunks, C >> 3)
 #define L(R, S) do { if (nt) L2(R, S, true); else L2(R, S, false); } while (0)
 #define LR(R) do { if (rmode == 2) L(R, 2); else if (rmode == 1) L(R, 1); else L(R, 0); } while (0)
     if (relu) LR(true); else LR(false);
@@ -812,6 +819,12 @@ extern "C" int ddl_bn_apply_fwd_ex(const void* y, const void* scale, const void*
 #undef L2
 #undef L
     return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_apply_fwd_ex(const void* y, const void* scale, const void* shift, const void* res,
+                                   const void* rscale, const void* rshift, void* z,
+                                   long long M, int C, int relu, hipStream_t stream) {
+    return ddl_bn_apply_fwd_ex2(y, scale, shift, res, rscale, rshift, z, nullptr, M, C, relu, stream);
 }
 
 extern "C" int ddl_bn_apply_fwd(const void* y, const void* scale, const void* shift, const void* res, void* z,

@@ -226,13 +226,15 @@ def _conv_fwd(x, w, stride, padding, want_stats):
 
 
 def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False, mask_src=None,
-                bn_y=None, bn_y2=None):
+                bn_y=None, bn_y2=None, mask_bits=None):
     """dx of a convolution; ``addend`` is summed in the epilogue (shortcut gradient) and
     ``mask_src`` (the ReLU output that IS the conv input) zeroes dx where it is <= 0.  With
     ``bn_y`` (the pre-BatchNorm tensor behind that ReLU; needs ``mask_src``) the kernel also
     emits that BatchNorm's backward partial sums and ``(dx, partial)`` is returned; ``bn_y2``
     (a second BatchNorm input fed by the same gradient: the projection shortcut's conv output)
-    adds a table of its own: ``(dx, partial, partial2)``."""
+    adds a table of its own: ``(dx, partial, partial2)``.  ``mask_bits`` (uint8, one bit per
+    element of ``mask_src > 0``, written by the forward BatchNorm apply) is read instead of
+    ``mask_src`` when given."""
     B, C, H, W = x_shape
     _, _, R, S = w.shape
     wt = _WT.get(w)
@@ -251,8 +253,10 @@ def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False,
         if bn_y2 is not None:
             partial2 = torch.empty((T, 2, C), dtype=torch.float32, device=dy.device)
     K.conv_igemm(dy, _geom(dy), wt, dx, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
-                 addend=addend, addend_sub2=addend_sub2, ep_mask=mask_src, ep_y=bn_y,
-                 stats=partial, ep_y2=bn_y2 if bn_y is not None else None, stats2=partial2)
+                 addend=addend, addend_sub2=addend_sub2,
+                 ep_mask=mask_src if mask_bits is None else None, ep_y=bn_y,
+                 stats=partial, ep_y2=bn_y2 if bn_y is not None else None, stats2=partial2,
+                 ep_maskbits=mask_bits if mask_src is not None else None)
     if bn_y is None:
         return dx
     return (dx, partial) if bn_y2 is None else (dx, partial, partial2)
@@ -506,11 +510,11 @@ def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True, part
 # allocation or a view) is 3-5 us of host time, ~30 of them per layer and step, and the host has
 # to keep ahead of ~50 us kernels in the late layers (profiles/r1_notes.md).
 def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentum, eps, relu,
-              apply=True, res_coeffs=None):
+              apply=True, res_coeffs=None, bits=None):
     """Training-mode conv -> BatchNorm(+residual)(+ReLU).  Returns (y, z, coeffs[4, C]).
     ``apply=False`` stops after the statistics (z is None): the caller folds this BatchNorm into
     a later kernel.  ``res_coeffs``: coefficient block of such a deferred BatchNorm whose raw conv
-    output is passed as ``residual``."""
+    output is passed as ``residual``.  ``bits``: uint8 buffer that receives ``z > 0`` bitwise."""
     B, C, H, W = x.shape
     Kc, Cw, R, S = w.shape
     if Cw != C:
@@ -536,9 +540,9 @@ def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentu
     if res_coeffs is not None:
         rb = res_coeffs.data_ptr()
         K.bn_apply_fwd(y, cb + 8 * Kc, cb + 12 * Kc, residual, z, M, Kc, relu,
-                       rb + 8 * Kc, rb + 12 * Kc)
+                       rb + 8 * Kc, rb + 12 * Kc, bits=bits)
     else:
-        K.bn_apply_fwd(y, cb + 8 * Kc, cb + 12 * Kc, residual, z, M, Kc, relu)
+        K.bn_apply_fwd(y, cb + 8 * Kc, cb + 12 * Kc, residual, z, M, Kc, relu, bits=bits)
     return y, z, coeffs
 
 
@@ -861,13 +865,21 @@ class ResidualBlockFn(Function):
                 shortcut, cd = _bn_fwd(yd, gd, bd, None, st, rmd, rvd, training, momentum, eps,
                                        False)
         cur = x
+        zbits_out = None
         for i in range(units):
             w, g, b, rm, rv = groups[i]
             last = i == units - 1
             if training:
+                zbits = None
+                if last and len(cfg) > 11 and cfg[11] is not None and _RELU_BITS["on"]:
+                    Ho = (cur.shape[2] + 2 * pads[i] - w.shape[2]) // strides[i] + 1
+                    Wo = (cur.shape[3] + 2 * pads[i] - w.shape[3]) // strides[i] + 1
+                    zbits = torch.empty(cur.shape[0] * Ho * Wo * w.shape[0] // 8, dtype=torch.uint8,
+                                        device=cur.device)
+                    zbits_out = zbits
                 y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, shortcut if last else None,
                                     rm, rv, momentum, eps, True,
-                                    res_coeffs=cd if (last and has_ds) else None)
+                                    res_coeffs=cd if (last and has_ds) else None, bits=zbits)
             else:
                 y, st = _conv_fwd(cur, w, strides[i], pads[i], training)
                 z, c = _bn_fwd(y, g, b, shortcut if last else None, st, rm, rv, training,
@@ -879,6 +891,7 @@ class ResidualBlockFn(Function):
         if len(cfg) > 11 and cfg[11] is not None:
             cfg[11].y = saved_y[-1]
             cfg[11].y2 = yd if (has_ds and training) else None
+            cfg[11].zbits = zbits_out
         ctx.cfg = cfg
         ctx.n_in = 2 + len(tensors)
         ctx.params = groups  # parameters/buffers are leaves: plain references are safe
@@ -970,9 +983,12 @@ class ResidualBlockFn(Function):
                     bn_y2 = link_in.y2 if (bn_y is not None and _FUSE_DS_REDUCE["on"]) else None
                     if bn_y2 is not None and bn_y2.shape != x.shape:
                         bn_y2 = None
+                    zbits = link_in.zbits if (premask_in and link_in is not None) else None
+                    if zbits is not None and zbits.numel() * 8 != x.numel():
+                        zbits = None
                     res = _conv_dgrad(dy, w, x.shape, strides[i], pads[i], addend=addend,
                                       addend_sub2=sub2, mask_src=x if premask_in else None,
-                                      bn_y=bn_y, bn_y2=bn_y2)
+                                      bn_y=bn_y, bn_y2=bn_y2, mask_bits=zbits)
                     if bn_y2 is not None:
                         grads[0], link_in.partial, link_in.partial2 = res
                     elif bn_y is not None:
@@ -991,6 +1007,9 @@ _FUSE_BN_REDUCE = {"on": True}
 # the projection shortcut's BatchNorm partials ride in the same epilogue (DDL_FUSE_DS_REDUCE=0:
 # separate reduce pass over the block's output gradient, the A/B switch)
 _FUSE_DS_REDUCE = {"on": _os.environ.get("DDL_FUSE_DS_REDUCE", "1") != "0"}
+# the ReLU mask between chained blocks travels as one bit per element (written by the forward
+# BatchNorm apply) instead of being re-read from the bf16 activation (DDL_RELU_BITS=0: re-read)
+_RELU_BITS = {"on": _os.environ.get("DDL_RELU_BITS", "1") != "0"}
 
 
 class _ChainLink:
@@ -998,13 +1017,14 @@ class _ChainLink:
     pre-BatchNorm output of its last unit (``y``) for the later block, whose backward returns
     the BatchNorm-backward partial sums (``partial``) computed in its input-gradient epilogue."""
 
-    __slots__ = ("y", "partial", "y2", "partial2")
+    __slots__ = ("y", "partial", "y2", "partial2", "zbits")
 
     def __init__(self):
         self.y = None
         self.partial = None
         self.y2 = None          # the earlier block's projection-shortcut conv output, if it has one
         self.partial2 = None    # ... and the partials of that BatchNorm (same gradient, other input)
+        self.zbits = None       # ReLU mask of the earlier block's output, one bit per element
 
 
 def residual_block(x, units, downsample, training, momentum, eps, premask_in=False,

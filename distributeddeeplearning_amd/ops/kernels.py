@@ -225,13 +225,15 @@ def storage_numel_from(x):
 
 def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil, Hout, Wout,
                addend=None, stats=None, addend_sub2=False, ep_y=None, ep_fcoef=None, ep_mask=None,
-               ep_y2=None, stats2=None):
+               ep_y2=None, stats2=None, ep_maskbits=None):
     """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel).
 
     Fused backward epilogues: ``ep_y`` + ``ep_fcoef`` (+ ``stats``) store the gradient masked by
     the ReLU of ``bn(ep_y)`` and emit the BatchNorm-backward partial sums per tile; ``ep_mask``
     zeroes the result where that tensor is <= 0; ``ep_y2`` + ``stats2`` (with ``ep_y`` and
-    ``ep_mask``): partial sums of a second BatchNorm fed by the same gradient."""
+    ``ep_mask``): partial sums of a second BatchNorm fed by the same gradient;
+    ``ep_maskbits`` (uint8, one bit per output element, from :func:`bn_apply_fwd`) replaces
+    ``ep_mask``."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
     for t in (ep_y, ep_mask, ep_y2):
         if t is not None and t.numel() != y.numel():
@@ -245,11 +247,13 @@ def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil,
             raise KernelError("conv_igemm: partial buffer too small for the fused reduce")
     if ep_y2 is not None and (stats2 is None or stats is None or stats2.numel() < stats.numel()):
         raise KernelError("conv_igemm: second partial buffer missing or too small")
-    f = _fn("ddl_conv_igemm_ex2", "ppppp qq iiii qqq iiiiiiiiii pppppp")
+    if ep_maskbits is not None and (ep_mask is not None or ep_maskbits.numel() * 8 < y.numel()):
+        raise KernelError("conv_igemm: ep_maskbits excludes ep_mask and must cover the output")
+    f = _fn("ddl_conv_igemm_ex2", "ppppp qq iiii qqq iiiiiiiiii ppppppp")
     check(f(x_ptr_tensor.data_ptr(), _p(w), y.data_ptr(), _p(addend), _p(stats), xn,
             w.numel(), B, Hin, Win, C, sb, sh, sw, Hout, Wout, n_out, R, S, ostride, pad, pad_w, idil,
             1 if addend_sub2 else 0, _p(ep_y), _p(ep_fcoef), _p(ep_mask), _p(ep_y2), _p(stats2),
-            _raw_stream()),
+            _p(ep_maskbits), _raw_stream()),
           "conv_igemm")
 
 
@@ -315,12 +319,15 @@ def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, scale, shift):
           "bn_eval_coeffs")
 
 
-def bn_apply_fwd(y, scale, shift, res, z, M, C, relu, res_scale=None, res_shift=None):
+def bn_apply_fwd(y, scale, shift, res, z, M, C, relu, res_scale=None, res_shift=None, bits=None):
     """z = act(y*scale + shift [+ res]); with ``res_scale``/``res_shift`` the residual is the raw
-    output of the projection conv and its BatchNorm is applied on the fly."""
-    f = _fn("ddl_bn_apply_fwd_ex", "ppppppp qii p")
+    output of the projection conv and its BatchNorm is applied on the fly.  ``bits`` (uint8,
+    M*C/8 bytes): also store ``z > 0`` as one bit per element."""
+    if bits is not None and bits.numel() * 8 < M * C:
+        raise KernelError("bn_apply_fwd: mask buffer too small")
+    f = _fn("ddl_bn_apply_fwd_ex2", "pppppppp qii p")
     check(f(y.data_ptr(), _p(scale), _p(shift), _p(res), _p(res_scale), _p(res_shift),
-            z.data_ptr(), M, C, 1 if relu else 0, _raw_stream()), "bn_apply_fwd")
+            z.data_ptr(), _p(bits), M, C, 1 if relu else 0, _raw_stream()), "bn_apply_fwd")
 
 
 @functools.lru_cache(maxsize=None)

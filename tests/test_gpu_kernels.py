@@ -140,6 +140,26 @@ def test_batchnorm_act(shape, relu, res):
         assert rms_relerr(r.grad, rr.grad) < 1e-2
 
 
+def test_bn_apply_writes_relu_bitmask():
+    """``bits`` of the forward BatchNorm apply: bit e of byte i = (z[8i + e] > 0)."""
+    from distributeddeeplearning_amd.ops import kernels as K
+    B, C, H, W = 5, 72, 9, 7
+    y = rand_nhwc(B, C, H, W, seed=51)
+    res = rand_nhwc(B, C, H, W, seed=52)
+    scale = torch.rand(C, device=DEV) + 0.5
+    shift = torch.randn(C, device=DEV) * 0.2
+    z = torch.empty_like(y)
+    bits = torch.zeros(B * H * W * C // 8, dtype=torch.uint8, device=DEV)
+    K.bn_apply_fwd(y, scale, shift, res, z, B * H * W, C, True, bits=bits)
+    z_ref = torch.empty_like(y)
+    K.bn_apply_fwd(y, scale, shift, res, z_ref, B * H * W, C, True)
+    assert torch.equal(z, z_ref)
+    zb = (z.permute(0, 2, 3, 1).reshape(-1, 8) > 0).to(torch.int32)
+    want = (zb << torch.arange(8, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    assert 0.2 < float((z > 0).float().mean()) < 0.8
+
+
 def test_batchnorm_eval():
     hip = _hip()
     B, C, H, W = 2, 128, 5, 5
@@ -322,6 +342,12 @@ def test_dgrad_fused_bn_reduce_and_relu_mask_epilogues(case):
         ps = part.sum(0)
         assert torch.allclose(ps[0], t1, rtol=1e-3, atol=1e-3 * float(t1.abs().max()))
         assert torch.allclose(ps[1], t2, rtol=1e-3, atol=1e-3 * float(t2.abs().max()))
+        # the same mask as one bit per element (as the forward BatchNorm apply writes it)
+        zb = (z.permute(0, 2, 3, 1).reshape(-1, 8) > 0).to(torch.int32)
+        bits = (zb << torch.arange(8, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
+        viabits = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad, addend=addend, mask_src=z,
+                                  mask_bits=bits)
+        assert torch.equal(viabits, masked)
         # a second BatchNorm fed by the same gradient (projection shortcut): its own table
         y2 = rand_nhwc(B, Cin, H, W, seed=35)
         both2, part_a, part_b = hip._conv_dgrad(dy, w, (B, Cin, H, W), stride, pad, addend=addend,
