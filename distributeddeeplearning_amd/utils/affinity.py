@@ -59,11 +59,12 @@ def _device_bdf(index: int) -> str | None:
 
 
 def bind_to_gpu_numa(device_index: int, sysfs: str = "/sys", bdf: str | None = None,
-                     min_cpus: int = 2) -> set[int] | None:
+                     min_cpus: int = 8) -> set[int] | None:
     """Restrict this process to the allowed CPUs on the GPU's NUMA node.
 
     Returns the new CPU set, or None when nothing was changed.  Never widens the current mask
-    (a container's cpuset stays in force) and never narrows it below ``min_cpus``.
+    (a container's cpuset stays in force) and never narrows it below ``min_cpus`` (a rank runs
+    its Python thread, the autograd thread, RCCL's proxy/watchdog threads and the loader).
     """
     if os.environ.get("HVD_NUMA_BIND", "1").strip().lower() in ("0", "false", "no", "off"):
         return None

@@ -199,9 +199,11 @@ def test_numa_affinity_helpers(tmp_path, monkeypatch):
     monkeypatch.setenv("HVD_NUMA_BIND", "0")
     assert A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf) is None and not calls
     monkeypatch.setenv("HVD_NUMA_BIND", "1")
-    got = A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf)
+    got = A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf, min_cpus=2)
     if len(allowed) >= 4:
         assert got == set(allowed[: len(allowed) // 2]) and calls == [got]
+    if len(allowed) // 2 < 8:  # the default refuses to squeeze a rank's threads onto < 8 CPUs
+        assert A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf) is None
     # unknown node (-1) and a node with no allowed CPU leave the mask alone
     (dev / "numa_node").write_text("-1\n")
     assert A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf) is None
