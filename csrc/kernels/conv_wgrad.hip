@@ -381,6 +381,8 @@ extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S) {
     else if (R * S >= 9) target = (C <= 64) ? 3072 : 896;
     else target = 1024;
     if (forced > 0) target = forced;
+    static const int scale_pct = getenv("DDL_WGRAD_TARGET_PCT") ? atoi(getenv("DDL_WGRAD_TARGET_PCT")) : 100;  // tuning knob
+    if (scale_pct > 0 && scale_pct != 100) target = (int)((long long)target * scale_pct / 100);
     long long want = (target + tiles - 1) / tiles;
     long long max_by_m = (M + 255) / 256;                  // at least 256 reduction rows per split
     if (want > max_by_m) want = max_by_m;

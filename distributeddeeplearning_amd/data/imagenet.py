@@ -40,7 +40,10 @@ def _pil():
     return Image
 
 
-def _to_tensor(img, normalize=True):
+def _to_tensor(img, normalize=True, raw_uint8=False):
+    if raw_uint8:  # CHW uint8: scaling + normalisation happen on the GPU (kernel K20, data/prefetch.py)
+        arr = np.asarray(img.convert("RGB"), dtype=np.uint8)
+        return torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
     arr = np.asarray(img.convert("RGB"), dtype=np.float32) / 255.0
     t = torch.from_numpy(arr).permute(2, 0, 1).contiguous()
     if normalize:
@@ -66,8 +69,10 @@ def _center_crop(img, size):
 
 
 def train_transform(size=224, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), normalize=True,
-                    rng=None):
-    """RandomResizedCrop(size) + RandomHorizontalFlip + ToTensor + Normalize."""
+                    rng=None, raw_uint8=False):
+    """RandomResizedCrop(size) + RandomHorizontalFlip + ToTensor + Normalize.  ``raw_uint8``: stop
+    after the flip and return the CHW uint8 pixels (a quarter of the bytes over PCIe; ToTensor and
+    Normalize then run on the GPU, ``data.prefetch.DevicePrefetcher``)."""
     rng = rng or random
 
     def apply(img):
@@ -97,7 +102,7 @@ def train_transform(size=224, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), n
         img = img.crop(box).resize((size, size), Image.BILINEAR)
         if rng.random() < 0.5:
             img = img.transpose(Image.FLIP_LEFT_RIGHT)
-        return _to_tensor(img, normalize)
+        return _to_tensor(img, normalize, raw_uint8)
 
     return apply
 
@@ -169,11 +174,11 @@ def _affine_nearest_fill(img, coeffs, size):
     return big.transform((size, size), Image.AFFINE, shifted, resample=Image.BILINEAR)
 
 
-def val_transform(resize=256, crop=224, normalize=True):
-    """Resize(256) + CenterCrop(224) + ToTensor + Normalize."""
+def val_transform(resize=256, crop=224, normalize=True, raw_uint8=False):
+    """Resize(256) + CenterCrop(224) + ToTensor + Normalize (``raw_uint8`` as in train_transform)."""
 
     def apply(img):
-        return _to_tensor(_center_crop(_resize_shorter(img, resize), crop), normalize)
+        return _to_tensor(_center_crop(_resize_shorter(img, resize), crop), normalize, raw_uint8)
 
     return apply
 

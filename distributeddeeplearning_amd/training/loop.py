@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 
 from .. import torch as hvd
-from ..data import DeviceSyntheticLoader, FakeData, get_sampler
+from ..data import DevicePrefetcher, DeviceSyntheticLoader, FakeData, get_sampler
 from ..data import imagenet as _imagenet
 from ..ops import functional as ops
 from ..utils.timer import Timer
@@ -158,7 +158,17 @@ def build_data(cfg, device, dtype, logger, world, rank):
 
     FAKE + GPU → the on-device Philox pool (K19); FAKE on CPU or ``DEVICE_DATA=False`` → the
     reference-semantics host ``FakeData`` through a DataLoader; otherwise ImageFolder loaders
-    with the reference's transforms (:284-316)."""
+    with the reference's transforms (:284-316).  Host loaders feeding a GPU are wrapped in a
+    :class:`DevicePrefetcher` (upload + layout/dtype conversion of the next batches on a copy
+    stream); real images then travel as uint8 and are normalised on the GPU."""
+    on_gpu = device.type == "cuda"
+    depth = getattr(cfg, "prefetch_depth", 2)
+
+    def wrap(loader):
+        if loader is None or not on_gpu or depth <= 0:
+            return loader
+        return DevicePrefetcher(loader, device, dtype, depth=depth)
+
     if cfg.fake:
         logger.info("Setting up fake loaders")
         if cfg.device_data and device.type == "cuda":
@@ -172,17 +182,19 @@ def build_data(cfg, device, dtype, logger, world, rank):
                       n_channels=cfg.channels, length=cfg.fake_data_length, seed=cfg.seed)
         sampler = get_sampler(ds, cfg.distributed, seed=cfg.seed)
         workers = 0 if device.type == "cpu" else cfg.num_workers
-        return _imagenet.make_loader(ds, cfg.batch_size, sampler, workers), None, len(ds), sampler
+        return wrap(_imagenet.make_loader(ds, cfg.batch_size, sampler, workers)), None, len(ds), sampler
     logger.info("Setting up loaders")
-    train_ds = _imagenet.ImageFolder(cfg.train_dir, _imagenet.train_transform(cfg.width))
+    raw = bool(on_gpu and depth > 0 and getattr(cfg, "uint8_transport", True))
+    train_ds = _imagenet.ImageFolder(cfg.train_dir, _imagenet.train_transform(cfg.width, raw_uint8=raw))
     sampler = get_sampler(train_ds, cfg.distributed, seed=cfg.seed)
-    train = _imagenet.make_loader(train_ds, cfg.batch_size, sampler, cfg.num_workers)
+    train = wrap(_imagenet.make_loader(train_ds, cfg.batch_size, sampler, cfg.num_workers))
     val = None
     if cfg.test_dir:
-        val_ds = _imagenet.ImageFolder(cfg.test_dir, _imagenet.val_transform(256, cfg.width))
-        val = _imagenet.make_loader(val_ds, cfg.batch_size,
-                                    get_sampler(val_ds, cfg.distributed, seed=cfg.seed),
-                                    cfg.num_workers)
+        val_ds = _imagenet.ImageFolder(cfg.test_dir,
+                                       _imagenet.val_transform(256, cfg.width, raw_uint8=raw))
+        val = wrap(_imagenet.make_loader(val_ds, cfg.batch_size,
+                                         get_sampler(val_ds, cfg.distributed, seed=cfg.seed),
+                                         cfg.num_workers))
     return train, val, len(train_ds), sampler
 
 

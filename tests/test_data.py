@@ -142,3 +142,28 @@ def test_keras_transforms():
     assert v.shape == (3, 32, 32)
     # zoom 0.875 about the centre keeps the centre pixel neighbourhood in place
     assert np.allclose(v.numpy()[:, 15:17, 15:17].mean(), ident.numpy()[:, 15:17, 15:17].mean(), atol=30)
+
+
+def test_device_prefetcher_cpu_passthrough_and_uint8_transport(tmp_path):
+    """data/prefetch.py on a CPU device: same batches in the same order, ``len`` and ``sampler``
+    forwarded; uint8 batches (``raw_uint8`` transforms) come out normalised like the float path."""
+    from PIL import Image
+    from distributeddeeplearning_amd.data import DevicePrefetcher
+    from distributeddeeplearning_amd.data import imagenet as im
+    from distributeddeeplearning_amd.utils.config import RGB_MEAN, RGB_SD
+
+    batches = [(torch.full((2, 3, 4, 4), float(i)), torch.tensor([i, i + 1])) for i in range(5)]
+    pf = DevicePrefetcher(batches, "cpu", dtype=torch.float32)
+    got = list(pf)
+    assert len(pf) == 5 and len(got) == 5
+    for (a, b), (c, d) in zip(batches, got):
+        assert torch.equal(a, c) and torch.equal(b, d)
+
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 256, size=(40, 48, 3), dtype=np.uint8))
+    raw = im.val_transform(32, 24, raw_uint8=True)(img)
+    ref = im.val_transform(32, 24)(img)
+    assert raw.dtype == torch.uint8 and raw.shape == (3, 24, 24)
+    out, _ = next(iter(DevicePrefetcher([(raw[None], torch.tensor([0]))], "cpu", dtype=torch.float32,
+                                        mean=RGB_MEAN, sd=RGB_SD)))
+    assert out.dtype == torch.float32 and torch.allclose(out[0], ref, atol=1e-6)

@@ -790,3 +790,31 @@ print('OK')
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
                          timeout=300, cwd=root)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-3000:]
+
+
+def test_device_prefetcher_uploads_and_converts_on_a_copy_stream():
+    """data/prefetch.py on the GPU: float and uint8 NCHW host batches arrive as channels_last bf16
+    (kernel K20 on the copy stream), in order, and the consumer needs no host sync."""
+    from distributeddeeplearning_amd.data import DevicePrefetcher
+    from distributeddeeplearning_amd.utils.config import RGB_MEAN, RGB_SD
+
+    g = torch.Generator().manual_seed(3)
+    f32 = [(torch.randn(6, 3, 32, 24, generator=g), torch.arange(6) + 10 * i) for i in range(5)]
+    got = []
+    for data, target in DevicePrefetcher(f32, DEV, dtype=BF, depth=2):
+        assert data.is_cuda and data.dtype == BF and data.is_contiguous(memory_format=CL)
+        got.append(((data.float() * 2).cpu(), target.cpu()))  # consume on the current stream
+    assert len(got) == 5
+    for (a, b), (c, d) in zip(f32, got):
+        assert torch.equal(b, d)
+        assert torch.allclose(c / 2, a.to(BF).float())
+    u8 = [(torch.randint(0, 256, (4, 3, 16, 16), dtype=torch.uint8, generator=g), torch.arange(4))
+          for _ in range(3)]
+    mean = torch.tensor(RGB_MEAN).view(1, 3, 1, 1)
+    sd = torch.tensor(RGB_SD).view(1, 3, 1, 1)
+    for (a, _), (c, _) in zip(u8, DevicePrefetcher(u8, DEV, dtype=BF, depth=3)):
+        want = (a.float() / 255.0 - mean) / sd
+        assert rms_relerr(c.float().cpu(), want) < 5e-3
+    # fp32 compute dtype: no kernel, same values
+    for (a, _), (c, _) in zip(u8, DevicePrefetcher(u8, DEV, dtype=torch.float32)):
+        assert torch.allclose(c.cpu(), (a.float() / 255.0 - mean) / sd, atol=1e-5)
