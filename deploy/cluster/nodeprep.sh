@@ -1,11 +1,13 @@
 #!/usr/bin/env bash
 # Node preparation for MI355X training nodes — counterpart of the reference's
-# cluster_config/nodeprep.sh + docker.service (8 GB default /dev/shm for DataLoader workers).
+# cluster_config/nodeprep.sh + docker.service (8 GB default /dev/shm for DataLoader workers),
+# done as a systemd drop-in over the distribution's unit instead of a replacement unit.
 # Run once per node, elevated.
 set -euo pipefail
 # 1. container runtime: large default shm (DataLoader workers collate through /dev/shm)
-if [ -d /lib/systemd/system ] && [ -f "$(dirname "$0")/docker.service" ]; then
-    cp "$(dirname "$0")/docker.service" /lib/systemd/system/docker.service
+dropin="$(dirname "$0")/docker.service.d/10-ddl-training.conf"
+if [ -d /etc/systemd/system ] && [ -f "$dropin" ] && systemctl cat docker.service >/dev/null 2>&1; then
+    install -D -m 0644 "$dropin" /etc/systemd/system/docker.service.d/10-ddl-training.conf
     systemctl daemon-reload && systemctl restart docker
 fi
 # 2. GPU access for the job user, and the dmabuf IPC mode RCCL needs on this stack
