@@ -721,7 +721,7 @@ class StemFn(Function):
         B, Kc, Ho, Wo = y.shape
         M = B * Ho * Wo
         dev = y.device
-        G = K.bn_bwd_blocks(M)
+        G = min(max(M // 64, 1), _STEM_REDUCE_BLOCKS)
         P = K._fold_slices(G) if G > 512 else 0
         tmp = torch.empty(3 * Kc + 2 * G * Kc + 2 * P * Kc, dtype=torch.float32, device=dev)
         coef = tmp.data_ptr()
@@ -751,6 +751,10 @@ class StemFn(Function):
         dw = torch.empty_like(w)
         dw.copy_(dwp[:, :, :7, :ctx.cin].permute(0, 3, 1, 2))
         return None, dw, dg, db, None, None, None, None
+
+
+# blocks of the stem's fused reduce pass (one [2][C] partial row each)
+_STEM_REDUCE_BLOCKS = int(_os.environ.get("DDL_STEM_REDUCE_BLOCKS", "4096"))
 
 
 def stem_supported(weight, stride, padding):
