@@ -402,6 +402,24 @@ def test_residual_chain_matches_unchained_blocks():
     o_a, dx_a, g_a = run(False)
     o_b, dx_b, g_b = run(True)
     assert torch.equal(o_a, o_b)
+    # the bit-packed ReLU mask is the same mask: switching it off changes nothing at all
+    hip._RELU_BITS["on"] = False
+    try:
+        o_c, dx_c, g_c = run(True)
+    finally:
+        hip._RELU_BITS["on"] = True
+    assert torch.equal(o_c, o_b) and torch.equal(dx_c, dx_b)
+    assert all(torch.equal(a, b) for a, b in zip(g_c, g_b))
+    # the projection BatchNorm's partials from the epilogue against the standalone reduce pass:
+    # same sums in another order
+    hip._FUSE_DS_REDUCE["on"] = False
+    try:
+        o_d, dx_d, g_d = run(True)
+    finally:
+        hip._FUSE_DS_REDUCE["on"] = True
+    assert rms_relerr(dx_d, dx_b) < 2e-3
+    for a, b in zip(g_d, g_b):
+        assert rms_relerr(a, b) < 2e-3
     # identical math up to the summation order of the BatchNorm partials (bf16 re-rounding of
     # dy then propagates): compare in rms
     assert rms_relerr(dx_b, dx_a) < 1e-2
