@@ -582,7 +582,10 @@ def _unit_bwd(dz, y, z, gamma, beta, coeffs, mask, want_g, partial=None):
         dg, db = dgb[0], dgb[1]
     dy = torch.empty_like(y)
     g = torch.empty_like(y) if (want_g and mask != 0) else None
-    K.bn_bwd_apply(dz, y, z if mask == 1 else None, fco, coef, dy, g, M, C, mask)
+    if _PROBE_SKIP_WIDE_APPLY and want_g and mask == 0:
+        pass  # timing-only probe (results are wrong): price of the wide unit's backward apply pass
+    else:
+        K.bn_bwd_apply(dz, y, z if mask == 1 else None, fco, coef, dy, g, M, C, mask)
     if want_g and mask == 0:
         g = dz
     if direct:
@@ -752,6 +755,10 @@ class StemFn(Function):
         dw.copy_(dwp[:, :, :7, :ctx.cin].permute(0, 3, 1, 2))
         return None, dw, dg, db, None, None, None, None
 
+
+# timing-only probe for the plan in profiles/r1_notes.md ("BatchNorm backward of the wide unit by
+# linearity"): DDL_PROBE_SKIP_WIDE_APPLY=1 drops that apply pass, gradients are then garbage
+_PROBE_SKIP_WIDE_APPLY = _os.environ.get("DDL_PROBE_SKIP_WIDE_APPLY", "0") == "1"
 
 # blocks of the stem's fused reduce pass (one [2][C] partial row each)
 _STEM_REDUCE_BLOCKS = int(_os.environ.get("DDL_STEM_REDUCE_BLOCKS", "4096"))
