@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--aten", action="store_true")
     ap.add_argument("--blaslt", action="store_true",
                     help="1x1 stride-1 shapes: also time the plain library GEMM (torch.matmul -> hipBLASLt)")
+    ap.add_argument("--epi4", action="store_true",
+                    help="also time backward-data of the 1x1 layers with the chain epilogue of the training "
+                         "step (shortcut addend + ReLU bit mask + BatchNorm partials) and report its traffic rate")
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
@@ -113,6 +116,23 @@ def main():
         tot["fwd"] += tf_ * count
         tot["dgrad"] += td * count
         tot["wgrad"] += tw * count
+        if args.epi4 and k == 1 and stride == 1 and cin >= 4 * cout:
+            # conv1 of a bottleneck block: dx [M, cin] = dy W + g_short, masked by the block input's
+            # ReLU bits, plus sum g / sum g*y3 of the previous block's last BatchNorm
+            addend = torch.randn_like(x)
+            y3 = torch.randn_like(x)
+            bits = torch.randint(0, 256, (x.numel() // 8,), dtype=torch.uint8, device=dev)
+            zsrc = torch.relu(torch.randn_like(x))
+
+            def epi4(mask_bits):
+                return lambda: hip_ops._conv_dgrad(dy, w, x.shape, 1, 0, addend=addend, mask_src=zsrc,
+                                                   bn_y=y3, mask_bits=mask_bits)
+
+            t4, t4z = timeit(epi4(bits), args.iters), timeit(epi4(None), args.iters)
+            moved = dy.numel() * 2 + 3 * x.numel() * 2 + bits.numel()
+            line += "\n     EPI-4 (bits) %7.1f us = %5.2f TB/s of %4.0f MB   (mask from the bf16 activation: %7.1f us)" % (
+                t4 * 1e3, moved / t4 / 1e9, moved / 1e6, t4z * 1e3)
+            row["epi4_us"], row["epi4_zmask_us"] = t4 * 1e3, t4z * 1e3
         if args.aten:
             xr = x.detach().requires_grad_(True)
             wr = w.detach().requires_grad_(True)
