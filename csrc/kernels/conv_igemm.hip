@@ -72,8 +72,11 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 //        backward needs neither the mask tensor nor a masked copy of the gradient;
 //      4 = 3 plus the sum g / sum g*y partials of the BatchNorm that feeds that ReLU (ep_y), and
 //        with ep_y2 also those of the projection shortcut's BatchNorm (same g, other y).
+#ifndef DDL_CONV_MIN_WAVES
+#define DDL_CONV_MIN_WAVES 2   // waves per SIMD the register allocation must allow (3 and 4 measured: profiles/r1_notes.md)
+#endif
 template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS>
-__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const IGemmParams p) {
+__global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WAVES : 2) conv_igemm_kernel(const IGemmParams p) {
     static_assert(BM % 128 == 0, "statistics rows are per 128 output rows");
     constexpr bool STATS = EPI == 1 || EPI == 2 || EPI == 4;
     constexpr int CPR = BK / 8;            // 16-byte chunks per tile row
