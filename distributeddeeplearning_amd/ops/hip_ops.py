@@ -338,8 +338,9 @@ def _conv_wgrad(dy, x, w, stride, padding):
 
 
 # ---- second stream for weight gradients --------------------------------------------------------
-_SIDE = {"on": True, "stream": None, "pending": False, "event": None, "ws": None, "keep": [], "join_queued": False}
 import os as _os
+_SIDE = {"on": _os.environ.get("DDL_WGRAD_SIDE_STREAM", "1") != "0",   # 0: weight gradients on the main stream
+         "stream": None, "pending": False, "event": None, "ws": None, "keep": [], "join_queued": False}
 _SIDE_LEAN = _os.environ.get("DDL_SIDE_LEAN", "1") != "0"
 
 

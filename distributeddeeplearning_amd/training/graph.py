@@ -10,9 +10,12 @@ on one node) no longer shows up in step time.
 
 What makes the framework's step capturable:
 
-* every hand-written kernel is launched on ``torch.cuda.current_stream()`` (the capture stream)
-  and the weight-gradient side stream forks from / joins it with events, which stream capture
-  follows (``ops/hip_ops.py``);
+* every hand-written kernel is launched on ``torch.cuda.current_stream()`` (the capture stream).
+  The weight-gradient side stream forks from / joins it with events, which stream capture does
+  follow - but ROCm 7.2 replays a graph with ~50 cross-stream edges at ~25 us per node (29 ms
+  for the 19 ms step, 13 ms even at batch 16), while the same step captured on one stream
+  replays at the speed of eager single-stream issue.  ``single_stream=True`` (default) therefore
+  records the weight gradients on the capture stream (same kernels, same order of every sum);
 * scratch memory comes from torch's allocator (private pool during capture), gradients are
   static views into the arenas (``parallel/bucket.py``), ``zero_grad`` is a memset node;
 * nothing in the step reads a value back to the host; the loss stays on the device;
@@ -41,7 +44,7 @@ __all__ = ["GraphedTrainStep"]
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, loss_fn, warmup: int = 3, allow_collectives: bool = False,
-                 enabled: bool = True):
+                 enabled: bool = True, single_stream: bool = True):
         """``loss_fn(model_output, labels) -> scalar tensor``; ``optimizer`` is a FusedSGD /
         FusedLARS (optionally wrapped by ``hvd.DistributedOptimizer``) or any optimizer whose
         ``step`` is capture-safe."""
@@ -49,6 +52,7 @@ class GraphedTrainStep:
         self.warmup = max(int(warmup), 1)
         self.allow_collectives = allow_collectives
         self.enabled = enabled
+        self.single_stream = single_stream
         self.calls = 0
         self.graph = None
         self.failed = None          # the exception that made capture fall back to eager
@@ -84,16 +88,23 @@ class GraphedTrainStep:
         self._static_in = (images.clone(), labels.clone())
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
+        from ..ops import hip_ops as _hip_ops
+
+        side_was_on = _hip_ops._SIDE["on"]
+        if self.single_stream:
+            _hip_ops.set_wgrad_side_stream(False)
         try:
             with torch.cuda.graph(g):
                 self._static_loss = self._eager(*self._static_in)
         except Exception as e:  # capture refused something: stay eager, say why
+            _hip_ops.set_wgrad_side_stream(side_was_on)
             self.failed = e
             self._static_in = self._static_loss = None
             torch.cuda.synchronize()
             warnings.warn("HIP graph capture of the training step failed (%s: %s); continuing "
                           "eagerly" % (type(e).__name__, e))
             return False
+        _hip_ops.set_wgrad_side_stream(side_was_on)
         self.graph = g
         return True
 
