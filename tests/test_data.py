@@ -167,3 +167,23 @@ def test_device_prefetcher_cpu_passthrough_and_uint8_transport(tmp_path):
     out, _ = next(iter(DevicePrefetcher([(raw[None], torch.tensor([0]))], "cpu", dtype=torch.float32,
                                         mean=RGB_MEAN, sd=RGB_SD)))
     assert out.dtype == torch.float32 and torch.allclose(out[0], ref, atol=1e-6)
+
+
+def test_build_data_wraps_host_loaders_only_on_gpu(tmp_path):
+    """training.build_data: on a CPU device host loaders come back bare (no prefetcher, float
+    batches); the prefetcher forwards ``len`` and ``sampler`` of a real DataLoader."""
+    import logging
+    from distributeddeeplearning_amd.data import DevicePrefetcher
+    from distributeddeeplearning_amd.training import build_data
+    from distributeddeeplearning_amd.utils import TrainConfig
+
+    cfg = TrainConfig(fake=True, fake_data_length=16, batch_size=4, device_data=False, num_workers=0,
+                      height=32, width=32)
+    train, val, n, sampler = build_data(cfg, torch.device("cpu"), torch.float32,
+                                        logging.getLogger("t"), 1, 0)
+    assert not isinstance(train, DevicePrefetcher) and val is None and n == 16
+    data, target = next(iter(train))
+    assert data.dtype == torch.float32 and tuple(data.shape) == (4, 3, 32, 32)
+    pf = DevicePrefetcher(train, "cpu", dtype=torch.float32)
+    assert len(pf) == len(train) == 4 and pf.sampler is train.sampler
+    assert sum(len(t) for _, t in pf) == 16
