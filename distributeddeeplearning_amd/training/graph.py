@@ -119,12 +119,15 @@ class GraphedTrainStep:
                 return self._eager(images, labels)
             # capture records, it does not execute: fall through and replay for this batch
         si, sl = self._static_in
+        if hasattr(self.optimizer, "sync_lr"):
+            self.optimizer.sync_lr()   # the frozen learning rate lives in a device scalar from now on
+        if images.shape != si.shape or labels.shape != sl.shape or images.dtype != si.dtype:
+            # e.g. the short last batch of an epoch: the graph is for one shape only
+            return self._eager(images, labels)
         if images.data_ptr() != si.data_ptr():
             si.copy_(images, non_blocking=True)
         if labels.data_ptr() != sl.data_ptr():
             sl.copy_(labels, non_blocking=True)
-        if hasattr(self.optimizer, "sync_lr"):
-            self.optimizer.sync_lr()
         self.graph.replay()
         return self._static_loss
 

@@ -516,6 +516,9 @@ def test_graphed_train_step_matches_eager():
             if i == 5:
                 opt.param_groups[0]["lr"] = 2.0 ** -8
             losses.append(float(step(x, t).detach().float()))
+        # a short last batch after capture runs eagerly (the graph is for one shape), then replay again
+        losses.append(float(step(xs[0][:8], ts[0][:8]).detach().float()))
+        losses.append(float(step(xs[1], ts[1]).detach().float()))
         torch.cuda.synchronize()
         assert step.graphed == graph, step.failed
         bn = model.bn1.running_mean.detach().clone()
@@ -526,7 +529,7 @@ def test_graphed_train_step_matches_eager():
     assert all(math.isfinite(v) for v in lg), lg
     assert le == lg, (le, lg)
     assert torch.equal(we, wg)
-    assert torch.equal(be, bg) and ne == ng == 8
+    assert torch.equal(be, bg) and ne == ng == 10
 
 
 def test_fused_sgd_matches_torch():
