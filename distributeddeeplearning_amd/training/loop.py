@@ -26,7 +26,7 @@ from ..ops import functional as ops
 from ..utils.timer import Timer
 
 __all__ = ["train_epoch", "validate", "log_summary", "to_device_batch", "build_data",
-           "build_optimizer"]
+           "build_optimizer", "build_graph_step"]
 
 _TRAIN_MSG = " duration({})  loss:{} total-samples: {}"
 _VAL_MSG = "validation duration({})  loss:{} total-samples: {}"
@@ -45,10 +45,28 @@ def to_device_batch(data, target, device, dtype):
     return data, target
 
 
+def build_graph_step(cfg, model, optimizer, criterion, device, world):
+    """A :class:`~.graph.GraphedTrainStep` for ``train_epoch(graph_step=...)`` or None.
+
+    ``cfg.hip_graph``: ``on`` | ``off`` | ``auto``.  Measured on MI355X (profiles/r1_notes.md): replay
+    beats eager issue where the host is the bottleneck (batch 16-32 per GPU: +24-28 %) and loses
+    3-6 % from batch 64 up, where the eager path's second stream is worth more than the saved
+    launches - so ``auto`` means one GPU, batch <= 32."""
+    mode = str(getattr(cfg, "hip_graph", "auto")).strip().lower()
+    if device.type != "cuda" or mode in ("off", "0", "false", "no"):
+        return None
+    if mode not in ("on", "1", "true", "yes") and not (world == 1 and cfg.batch_size <= 32):
+        return None
+    from .graph import GraphedTrainStep
+
+    return GraphedTrainStep(model, optimizer, criterion, warmup=3)
+
+
 def train_epoch(loader, model, criterion, optimizer, epoch, logger, device, dtype,
-                log_interval=100, metrics=None, callbacks=None, max_steps=0):
+                log_interval=100, metrics=None, callbacks=None, max_steps=0, graph_step=None):
     """One epoch of the reference hot loop (:210-221).  Returns a dict with the last logged
-    loss, the number of samples this rank processed and steady-state timing."""
+    loss, the number of samples this rank processed and steady-state timing.  ``graph_step``
+    (:func:`build_graph_step`) replaces the four calls of the step by one graph replay."""
     t = Timer()
     t.start()
     logger.set_epoch(epoch)
@@ -63,11 +81,14 @@ def train_epoch(loader, model, criterion, optimizer, epoch, logger, device, dtyp
         if callbacks is not None:
             callbacks.on_batch_begin(i)
         data, target = to_device_batch(data, target, device, dtype)
-        optimizer.zero_grad()
-        output = model(data)
-        loss = criterion(output, target)
-        loss.backward()
-        optimizer.step()
+        if graph_step is not None:
+            loss = graph_step(data, target)
+        else:
+            optimizer.zero_grad()
+            output = model(data)
+            loss = criterion(output, target)
+            loss.backward()
+            optimizer.step()
         n = len(data)
         samples += n
         if steady_on:

@@ -93,6 +93,7 @@ class TrainConfig:
     device_data: bool = True  # on-GPU synthetic generator instead of the host FakeData loader
     prefetch_depth: int = 2  # host batches uploaded + converted ahead on a copy stream (0 = off)
     uint8_transport: bool = True  # real data: ship uint8 pixels, normalise on the GPU (K20)
+    hip_graph: str = "auto"  # whole step as one HIP graph: on | off | auto (one GPU, batch <= 32)
     resume: bool = True
     metrics_path: Optional[str] = None
     max_steps: int = 0  # 0 = whole epoch
@@ -121,6 +122,7 @@ class TrainConfig:
             device_data=env_bool("DEVICE_DATA", True),
             prefetch_depth=env_int("PREFETCH_DEPTH", 2),
             uint8_transport=env_bool("UINT8_TRANSPORT", True),
+            hip_graph=env_str("HIP_GRAPH", "auto"),
             resume=env_bool("RESUME", True),
             metrics_path=env_str("METRICS_PATH", None),
             max_steps=env_int("MAX_STEPS", 0),

@@ -21,8 +21,8 @@ import torch  # noqa: E402
 
 import distributeddeeplearning_amd.torch as hvd  # noqa: E402
 from distributeddeeplearning_amd.models import build_model  # noqa: E402
-from distributeddeeplearning_amd.training import (build_data, build_optimizer, log_summary,  # noqa: E402
-                                                  train_epoch, validate)
+from distributeddeeplearning_amd.training import (build_data, build_graph_step, build_optimizer,  # noqa: E402
+                                                  log_summary, train_epoch, validate)
 from distributeddeeplearning_amd.training.loop import default_criterion  # noqa: E402
 from distributeddeeplearning_amd.utils import MetricsWriter, Timer, TrainConfig, get_logger  # noqa: E402
 from distributeddeeplearning_amd.utils import checkpoint  # noqa: E402
@@ -68,6 +68,8 @@ def main(argv=None):
     metrics = MetricsWriter(cfg.metrics_path)
     criterion = default_criterion
 
+    # HIP_GRAPH=auto: one GPU and a small batch -> the step is replayed as one HIP graph
+    graph_step = build_graph_step(cfg, model, optimizer, criterion, device, world)
     logger.info("Training ...")
     for epoch in range(start_epoch, cfg.epochs):
         with Timer(output=logger.info, prefix="Training") as t:
@@ -77,7 +79,8 @@ def main(argv=None):
             if hasattr(train_loader, "set_epoch"):
                 train_loader.set_epoch(epoch)
             stats = train_epoch(train_loader, model, criterion, optimizer, epoch, logger, device,
-                                dtype, cfg.log_interval, metrics, max_steps=cfg.max_steps)
+                                dtype, cfg.log_interval, metrics, max_steps=cfg.max_steps,
+                                graph_step=graph_step)
         seen = stats["samples"] * world if cfg.max_steps else data_length
         log_summary(logger, seen, t.elapsed, cfg.batch_size, cfg.distributed, cfg.fake, stats)
         metrics.write(kind="epoch", epoch=epoch, seconds=t.elapsed, images_per_sec=seen / t.elapsed)
