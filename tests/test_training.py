@@ -123,3 +123,21 @@ def test_graphed_train_step_runs_eagerly_without_a_gpu():
     assert got == ref
     for a, b in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(a, b)
+
+
+def test_build_graph_step_policy():
+    """training.build_graph_step: never on a CPU device; on a GPU ``auto`` means one rank and a
+    per-GPU batch of at most 32, ``on`` / ``off`` force it (the device is only inspected by type)."""
+    import torch
+    from distributeddeeplearning_amd.training import build_graph_step
+    from distributeddeeplearning_amd.training.graph import GraphedTrainStep
+    from distributeddeeplearning_amd.utils import TrainConfig
+
+    cpu, gpu = torch.device("cpu"), torch.device("cuda", 0)
+    mk = lambda mode, bs: TrainConfig(hip_graph=mode, batch_size=bs)  # noqa: E731
+    assert build_graph_step(mk("on", 16), None, None, None, cpu, 1) is None
+    assert build_graph_step(mk("off", 16), None, None, None, gpu, 1) is None
+    assert build_graph_step(mk("auto", 64), None, None, None, gpu, 1) is None
+    assert build_graph_step(mk("auto", 16), None, None, None, gpu, 2) is None
+    assert isinstance(build_graph_step(mk("auto", 32), None, None, None, gpu, 1), GraphedTrainStep)
+    assert isinstance(build_graph_step(mk("on", 256), None, None, None, gpu, 8), GraphedTrainStep)
