@@ -198,6 +198,11 @@ def main(argv=None):
             "ops_backend": "hip" if (use_cuda and ops.backend() != "aten") else "aten",
             "hip_graph": bool(graphed is not None and graphed.graphed),
             "reserved_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1) if use_cuda else 0.0,
+            # gradient exchange: which engine carried it, how long the compute stream sat waiting for
+            # it per step (HIP events) and the device time of each bucket's collective
+            "engine": hvd.engine_name() if hvd.comm() is not None else "none",
+            "allreduce_algo": getattr(hvd.comm(), "algo", "rccl") if hvd.comm() is not None else "none",
+            "comm": opt.comm_metrics() if hasattr(opt, "comm_metrics") else None,
             "config": {"model": args.model, "global_batch": global_batch,
                        "per_gpu_batch": args.batch, "image": args.image,
                        "optimizer": args.optimizer, "parallelism": "dp%d" % world},

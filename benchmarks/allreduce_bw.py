@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     a = ap.parse_args()
+    os.environ.setdefault("HVD_ALLREDUCE_ALGO", a.algo)   # twoshot / oneshot: the direct xGMI kernel of the native engine
     hvd.init()
     cuda = torch.cuda.is_available()
     dev = torch.device("cuda", torch.cuda.current_device()) if cuda else torch.device("cpu")
@@ -39,17 +40,12 @@ def main():
         numel = int(mib * (1 << 20)) // torch.empty((), dtype=dt).element_size()
         numel = max(numel // (8 * 8 * n) * (8 * 8 * n), 8 * 8 * n)
         buf = torch.ones(numel, dtype=dt, device=dev)
-        direct = None
-        if a.algo != "rccl":
-            from distributeddeeplearning_amd.parallel.xgmi import XgmiAllreduce
-
-            direct = XgmiAllreduce(buf)
+        comm = hvd.comm()
+        if a.algo != "rccl" and comm is not None and hasattr(comm, "register_region"):
+            comm.register_region(buf)   # collective: peer-map this buffer on every rank
 
         def once():
-            if direct is not None:
-                direct.allreduce_(average=True, algo=a.algo)
-            else:
-                hvd.synchronize(hvd.allreduce_async_(buf, average=True, name="bw"))
+            hvd.synchronize(hvd.allreduce_async_(buf, average=True, name="bw.%d" % numel))
 
         for _ in range(3):
             once()
@@ -69,10 +65,13 @@ def main():
         if hvd.rank() == 0:
             print("%10d B  %10.1f us  alg %8.2f GB/s  bus %8.2f GB/s  %s" % (
                 nbytes, row["us"], row["algbw_GBps"], row["busbw_GBps"], "ok" if row["ok"] else "WRONG"))
-        if direct is not None:
-            direct.check_timeout()
+        if comm is not None and hasattr(comm, "failed") and comm.failed():
+            raise RuntimeError("the engine reported a failed collective: %s" % comm.last_error())
     if hvd.rank() == 0:
-        print(json.dumps({"algo": a.algo, "world": n, "rows": rows}))
+        extra = {}
+        if comm is not None and hasattr(comm, "launch_counts"):
+            extra = {"launches": comm.launch_counts(), "device_ms": {k: v["mean_ms"] for k, v in comm.stats().items()}}
+        print(json.dumps({"algo": a.algo, "world": n, "engine": hvd.engine_name(), "rows": rows, **extra}))
     hvd.shutdown()
 
 

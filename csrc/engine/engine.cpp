@@ -34,6 +34,7 @@
 #include <thread>
 #include <vector>
 
+#include "device_plane.h"
 #include "store.h"
 
 namespace ddl {
@@ -65,6 +66,42 @@ static inline uint16_t f_to_bf16(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+// IEEE binary16 <-> float (round to nearest even); the host ring reduces fp16 in fp32 like bf16
+static inline float f16_to_f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, u;
+    if (exp == 0) {
+        if (man == 0) u = sign;
+        else {  // subnormal: normalise
+            int e = -1;
+            do { ++e; man <<= 1; } while (!(man & 0x400u));
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) u = sign | 0x7f800000u | (man << 13);
+    else u = sign | ((exp + 112u) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+static inline uint16_t f_to_f16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);           // NaN
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          // overflow (incl. inf) -> inf
+    if (a < 0x33000001u) return sign;                                 // underflow -> signed zero
+    int exp = (int)(a >> 23) - 127;
+    uint32_t man = (a & 0x7fffffu) | 0x800000u;
+    int shift = exp < -14 ? 13 + (-14 - exp) : 13;                    // subnormal halves lose more bits
+    uint32_t half = exp < -14 ? 0u : (uint32_t)(exp + 15) << 10;
+    uint32_t m = man >> shift, rem = man & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+    if (exp >= -14) m &= 0x3ffu;
+    uint32_t r = half + m;                                            // mantissa carry rolls into the exponent
+    if (rem > mid || (rem == mid && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+
 template <typename T>
 static void reduce_typed(T* dst, const T* src, size_t n, int op) {
     if (op == MIN) for (size_t i = 0; i < n; ++i) dst[i] = src[i] < dst[i] ? src[i] : dst[i];
@@ -88,6 +125,16 @@ static void reduce_into(void* dst, const void* src, size_t n, int dt, int op) {
             }
             break;
         }
+        case F16: {
+            uint16_t* d = (uint16_t*)dst;
+            const uint16_t* s = (const uint16_t*)src;
+            for (size_t i = 0; i < n; ++i) {
+                float a = f16_to_f(d[i]), b = f16_to_f(s[i]);
+                float r = op == MIN ? (b < a ? b : a) : op == MAX ? (b > a ? b : a) : a + b;
+                d[i] = f_to_f16(r);
+            }
+            break;
+        }
         default: break;
     }
 }
@@ -98,6 +145,8 @@ static void scale_avg(void* buf, size_t n, int dt, int world) {
         case I64: { int64_t* p = (int64_t*)buf; for (size_t i = 0; i < n; ++i) p[i] = (int64_t)std::floor((double)p[i] / world); break; }
         case I32: { int32_t* p = (int32_t*)buf; for (size_t i = 0; i < n; ++i) p[i] = (int32_t)std::floor((double)p[i] / world); break; }
         case BF16: { uint16_t* p = (uint16_t*)buf; float s = 1.f / world; for (size_t i = 0; i < n; ++i) p[i] = f_to_bf16(bf16_to_f(p[i]) * s); break; }
+        case F16: { uint16_t* p = (uint16_t*)buf; float s = 1.f / world; for (size_t i = 0; i < n; ++i) p[i] = f_to_f16(f16_to_f(p[i]) * s); break; }
+        case U8: { uint8_t* p = (uint8_t*)buf; for (size_t i = 0; i < n; ++i) p[i] = (uint8_t)(p[i] / world); break; }
         default: break;
     }
 }
@@ -120,7 +169,23 @@ struct Op {
     std::string name;
     int64_t handle;
     double t_enqueue;
+    bool device = false;   // device memory: launched on the device plane's stream by the comm thread
+    DeviceOp dop;
 };
+
+// A device collective between its launch and the moment both the watchdog has seen it complete
+// and the consumer has queued its stream wait (the events are recycled only then).
+struct Inflight {
+    DeviceTicket ticket;
+    std::string name;
+    double t_launch = 0.0;
+    bool completed = false, released = false, warned = false;
+};
+
+struct CollectiveStat { long long count = 0; double total_ms = 0.0, last_ms = 0.0; int algo = 0; long long bytes = 0; };
+
+static const DevicePlane* g_plane = nullptr;
+void set_device_plane(const DevicePlane* plane) { g_plane = plane; }
 
 struct Header { uint32_t magic; int32_t kind, dtype; int64_t count; uint64_t name_hash; };
 
@@ -138,14 +203,17 @@ public:
         const int tmo = (int)(timeout_s * 1000);
         if (rank == 0) {
             int bound = 0;
-            server_ = store_server_start(port, &bound);
+            // a single-node job (the rendezvous address is the loopback interface) keeps its control
+            // plane off the network; multi-node jobs listen on every interface
+            const bool loopback = addr == "127.0.0.1" || addr == "localhost";
+            server_ = store_server_start(port, &bound, loopback);
             if (!server_) { *err = "cannot listen on control port " + std::to_string(port); return false; }
         }
         if (!store_.connect_to(addr, port, tmo)) { *err = "cannot reach the rendezvous store at " + addr; return false; }
         if (size > 1) {
             // ring wiring: publish my data port, connect to next, accept from prev
             int dport = 0;
-            listen_fd_ = tcp_listen(0, &dport);
+            listen_fd_ = tcp_listen(0, &dport, addr == "127.0.0.1" || addr == "localhost");
             if (listen_fd_ < 0) { *err = "cannot open a data socket"; return false; }
             char host[256] = {0};
             const char* adv = getenv("DDL_ADVERTISE_ADDR");
@@ -180,6 +248,11 @@ public:
         cv_.notify_all();
         if (worker_.joinable()) worker_.join();
         if (watchdog_.joinable()) watchdog_.join();
+        if (g_plane) {
+            std::lock_guard<std::mutex> g(mu_);
+            for (auto& kv : inflight_) g_plane->recycle(&kv.second.ticket);
+            inflight_.clear();
+        }
         timeline_stop();
         if (send_fd_ >= 0) ::close(send_fd_);
         if (recv_fd_ >= 0) ::close(recv_fd_);
@@ -203,7 +276,65 @@ public:
     int poll(int64_t h) {
         std::lock_guard<std::mutex> g(mu_);
         auto it = status_.find(h);
-        return it == status_.end() ? -1 : it->second;
+        if (it == status_.end()) return -1;
+        if (it->second == RUNNING) {  // a launched device collective: ask its completion event
+            auto f = inflight_.find(h);
+            if (f != inflight_.end() && g_plane && (f->second.completed || g_plane->query(f->second.ticket) == 1)) return DONE;
+        }
+        return it->second;
+    }
+
+    // Device collectives: the consumer's stream waits for the collective, the host only waits
+    // until the comm thread has LAUNCHED it (microseconds).  0 = ordered, 1 = timeout (not yet
+    // launched), 2 = failed (a peer died, a collective timed out ...), -1 = unknown handle.
+    // `order` false: bookkeeping only (the host already saw the completion event).  A null
+    // consumer_stream with `order` true is HIP's default stream - torch's default stream IS that.
+    int device_wait(int64_t h, void* consumer_stream, double timeout_s_, std::string* err, bool order = true) {
+        std::unique_lock<std::mutex> lk(mu_);
+        auto launched = [&] { auto it = status_.find(h); return it == status_.end() || it->second >= RUNNING; };
+        if (!done_cv_.wait_for(lk, std::chrono::duration<double>(timeout_s_), launched)) return 1;
+        auto it = status_.find(h);
+        if (it == status_.end()) return -1;
+        if (it->second == FAILED) { *err = last_error_; status_.erase(it); inflight_.erase(h); return 2; }
+        auto f = inflight_.find(h);
+        if (f == inflight_.end() || !g_plane) return -1;
+        const bool ok = !order || g_plane->wait_on(f->second.ticket, consumer_stream);
+        f->second.released = true;
+        if (f->second.completed) { g_plane->recycle(&f->second.ticket); inflight_.erase(f); }
+        status_.erase(it);
+        if (!ok) { *err = "hipStreamWaitEvent failed"; return 2; }
+        if (device_failed_.load()) { *err = last_error_; return 2; }
+        return 0;
+    }
+
+    // host-blocking completion of a device collective (tests, shutdown paths, hvd.synchronize on
+    // a handle whose result the HOST reads next)
+    int device_wait_host(int64_t h, double timeout_s_, std::string* err) {
+        const double t0 = now_us();
+        for (;;) {
+            int st = poll(h);
+            if (st == -1) return -1;
+            if (st == FAILED || device_failed_.load()) { std::lock_guard<std::mutex> g(mu_); *err = last_error_; return 2; }
+            if (st == DONE) break;
+            if ((now_us() - t0) * 1e-6 > timeout_s_) return 1;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        return device_wait(h, nullptr, timeout_s_, err, false);
+    }
+
+    bool failed() const { return device_failed_.load(); }
+
+    // "name count last_ms mean_ms algo bytes" per line: device time of every named collective
+    std::string stats_text() {
+        std::lock_guard<std::mutex> g(mu_);
+        std::string out;
+        char line[320];
+        for (auto& kv : stats_) {
+            snprintf(line, sizeof(line), "%s %lld %.4f %.4f %d %lld\n", kv.first.c_str(), kv.second.count, kv.second.last_ms,
+                     kv.second.count ? kv.second.total_ms / kv.second.count : 0.0, kv.second.algo, kv.second.bytes);
+            out += line;
+        }
+        return out;
     }
 
     // 0 = done, 1 = timeout, 2 = failed, -1 = unknown handle
@@ -270,6 +401,10 @@ private:
     FILE* tl_ = nullptr;
     bool tl_first_ = true;
     std::vector<char> scratch_;
+    std::map<int64_t, Inflight> inflight_;        // guarded by mu_
+    std::map<std::string, CollectiveStat> stats_; // guarded by mu_
+    std::atomic<bool> device_failed_{false};
+    bool comm_bound_ = false;
 
     void fail_all(const std::string& why) {
         std::lock_guard<std::mutex> g(mu_);
@@ -290,6 +425,7 @@ private:
                 std::unique_lock<std::mutex> lk(mu_);
                 if (cv_.wait_for(lk, std::chrono::milliseconds(period_ms), [&] { return !running_; })) return;
             }
+            watch_device();
             const double st = current_start_.load();
             if (st <= 0.0) { warned = false; continue; }
             const double el = (now_us() - st) * 1e-6;
@@ -310,6 +446,62 @@ private:
                 if (send_fd_ >= 0) ::shutdown(send_fd_, SHUT_RDWR);
                 if (recv_fd_ >= 0) ::shutdown(recv_fd_, SHUT_RDWR);
             }
+        }
+    }
+
+    // Device collectives in flight: completion (-> per-collective device time), stall warning, and
+    // the hard timeout.  A collective that does not finish within `timeout_s` (a dead or wedged
+    // peer) is aborted and every handle fails: synchronize() raises instead of hanging.
+    bool watch_bound_ = false;
+    void watch_device() {
+        if (!g_plane) return;
+        std::string dead;
+        double dead_for = 0.0;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            // a kernel that gave up on a peer (bounded spins) has already completed: its ticket may
+            // be gone, the host-visible timeout word is what is left of it
+            const bool ktmo = g_plane->kernel_timeout() != 0;
+            if (ktmo && inflight_.empty()) dead = "xgmi all-reduce (a peer never arrived: spin limit reached)";
+            if (inflight_.empty() && !ktmo) return;
+            if (!watch_bound_) watch_bound_ = g_plane->bind_thread();
+            const double now = now_us();
+            for (auto it = inflight_.begin(); it != inflight_.end();) {
+                Inflight& f = it->second;
+                if (!f.completed) {
+                    const int q = g_plane->query(f.ticket);
+                    if (q == 1 && !ktmo) {
+                        f.completed = true;
+                        const float ms = g_plane->elapsed_ms(f.ticket);
+                        auto& st = stats_[f.name];
+                        ++st.count; st.last_ms = ms; st.total_ms += ms;
+                        timeline_event(f.name, "DEVICE_DONE", 'i', now);
+                    } else {
+                        const double el = (now - f.t_launch) * 1e-6;
+                        if (el > stall_warning_s && !f.warned) {
+                            fprintf(stderr, "[ddl engine rank %d] WARNING: device collective '%s' has been in flight for %.1f s\n",
+                                    rank, f.name.c_str(), el);
+                            f.warned = true;
+                            ++stall_warnings;
+                        }
+                        if (q < 0 || ktmo || el > timeout_s) { dead = f.name; dead_for = el; break; }
+                    }
+                }
+                if (f.completed && f.released) {
+                    g_plane->recycle(&f.ticket);
+                    it = inflight_.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
+        if (!dead.empty() && !device_failed_.exchange(true)) {
+            char why[320];
+            snprintf(why, sizeof(why), "device collective '%s' did not complete within %.1f s (in flight for %.1f s); aborting the communicator",
+                     dead.c_str(), timeout_s, dead_for);
+            fprintf(stderr, "[ddl engine rank %d] ERROR: %s\n", rank, why);
+            g_plane->abort(why);
+            fail_all(why);
         }
     }
 
@@ -411,13 +603,44 @@ private:
                 if (!running_ && queue_.empty()) return;
                 op = std::move(queue_.front());
                 queue_.pop_front();
-                status_[op.handle] = RUNNING;
+                if (!op.device) status_[op.handle] = RUNNING;
             }
             {
                 std::lock_guard<std::mutex> g(cur_mu_);
                 current_name_ = op.name;
             }
             const double t0 = now_us();
+            if (op.device) {
+                // device collective: launch only (stream-ordered), completion is the watchdog's and
+                // the consumer stream's business; the comm thread goes straight on to the next op
+                std::string derr;
+                Inflight fl;
+                fl.name = op.name;
+                bool ok = g_plane != nullptr;
+                if (ok && !comm_bound_) { ok = g_plane->bind_thread(); comm_bound_ = ok; }
+                if (!ok) derr = "no device plane attached to the engine";
+                else ok = g_plane->launch(op.dop, &fl.ticket, &derr);
+                fl.t_launch = now_us();
+                timeline_event(op.name, op.dop.algo == ALGO_RCCL ? "RCCL_LAUNCH" : "XGMI_LAUNCH", 'i', fl.t_launch);
+                if (!ok) {
+                    {
+                        std::lock_guard<std::mutex> g(mu_);
+                        status_[op.handle] = FAILED;
+                    }
+                    fail_all("device collective '" + op.name + "' could not be launched: " + derr);
+                    continue;
+                }
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    auto& st = stats_[op.name];
+                    st.algo = fl.ticket.algo;
+                    st.bytes = op.count * (long long)dtype_size(op.dtype);
+                    inflight_[op.handle] = fl;
+                    status_[op.handle] = RUNNING;
+                }
+                done_cv_.notify_all();
+                continue;
+            }
             current_start_.store(t0);
             timeline_event(op.name, op.kind == ALLREDUCE ? "ALLREDUCE" : op.kind == BROADCAST ? "BROADCAST"
                                    : op.kind == ALLGATHER ? "ALLGATHER" : "BARRIER", 'B', t0);
@@ -508,6 +731,43 @@ long long ddl_eng_barrier_async(const char* name) {
     ddl::Op op{ddl::ALLREDUCE, ddl::I64, ddl::SUM, 0, &token, nullptr, 1, name ? name : "barrier", 0, 0.0};
     return g_engine->submit(std::move(op));
 }
+// Device collective through the engine: the submitting thread records the readiness event on its
+// producer stream, the comm thread launches on the device plane's stream (rccl_backend.cpp).
+// kind: 0 all-reduce, 1 broadcast, 2 all-gather; algo: 0 RCCL, 1 xGMI two-shot, 2 xGMI one-shot.
+long long ddl_eng_device_collective(int kind, void* buf, void* out, long long count, int dtype, int redop, int root,
+                                    int algo, void* producer_stream, const char* name) {
+    if (!g_engine) return -1;
+    if (!ddl::g_plane) { g_err = "device tensor given but no device plane is attached (RCCL backend not initialised)"; return -1; }
+    if (kind < 0 || kind > 2 || !buf || count < 0 || (kind == ddl::ALLGATHER && !out) ||
+        (kind == ddl::BROADCAST && (root < 0 || root >= g_engine->size))) { g_err = "invalid device collective"; return -1; }
+    if (g_engine->failed()) { g_err = "the engine has failed; no further collectives are accepted"; return -1; }
+    ddl::Op op{kind, dtype, redop, root, buf, out, count, name ? name : "", 0, 0.0};
+    op.device = true;
+    op.dop.kind = kind; op.dop.dtype = dtype; op.dop.redop = redop; op.dop.root = root; op.dop.algo = algo;
+    op.dop.buf = buf; op.dop.out = out; op.dop.count = count;
+    op.dop.ready = ddl::g_plane->record_ready(producer_stream);
+    if (!op.dop.ready) { g_err = "readiness event could not be recorded"; return -1; }
+    return g_engine->submit(std::move(op));
+}
+int ddl_eng_device_wait(long long handle, void* consumer_stream, double timeout_s) {
+    if (!g_engine) return -1;
+    return g_engine->device_wait(handle, consumer_stream, timeout_s, &g_err);
+}
+int ddl_eng_device_wait_host(long long handle, double timeout_s) {
+    if (!g_engine) return -1;
+    return g_engine->device_wait_host(handle, timeout_s, &g_err);
+}
+int ddl_eng_failed() { return g_engine && g_engine->failed() ? 1 : 0; }
+// per-collective device times ("name count last_ms mean_ms algo bytes" lines); returns the length
+long long ddl_eng_stats(char* buf, long long cap) {
+    if (!g_engine || !buf || cap <= 0) return -1;
+    const std::string t = g_engine->stats_text();
+    const long long n = (long long)t.size() < cap - 1 ? (long long)t.size() : cap - 1;
+    std::memcpy(buf, t.data(), (size_t)n);
+    buf[n] = 0;
+    return n;
+}
+
 int ddl_eng_poll(long long handle) { return g_engine ? g_engine->poll(handle) : -1; }
 int ddl_eng_wait(long long handle, double timeout_s) {
     if (!g_engine) return -1;
@@ -526,6 +786,11 @@ long long ddl_eng_store_get(const char* key, int timeout_ms) {  // returns lengt
     return g_engine->store().get(key, &g_buf, timeout_ms) ? (long long)g_buf.size() : -1;
 }
 const void* ddl_eng_store_data() { return g_buf.data(); }
+int ddl_eng_store_del(const char* key) {
+    if (!g_engine) return -1;
+    std::lock_guard<std::mutex> g(g_engine->store_mu);
+    return g_engine->store().del(key) ? 0 : -1;
+}
 long long ddl_eng_store_add(const char* key, long long delta) {
     if (!g_engine) return -1;
     std::lock_guard<std::mutex> g(g_engine->store_mu);

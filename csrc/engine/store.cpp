@@ -73,14 +73,14 @@ bool recv_all(int fd, void* buf, size_t n, int timeout_ms) {
     return true;
 }
 
-int tcp_listen(int port, int* bound_port) {
+int tcp_listen(int port, int* bound_port, bool loopback_only) {
     int fd = ::socket(AF_INET, SOCK_STREAM, 0);
     if (fd < 0) return -1;
     int one = 1;
     setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
     sockaddr_in addr{};
     addr.sin_family = AF_INET;
-    addr.sin_addr.s_addr = htonl(INADDR_ANY);
+    addr.sin_addr.s_addr = htonl(loopback_only ? INADDR_LOOPBACK : INADDR_ANY);
     addr.sin_port = htons((uint16_t)port);
     if (::bind(fd, (sockaddr*)&addr, sizeof(addr)) != 0 || ::listen(fd, 256) != 0) {
         ::close(fd);
@@ -211,9 +211,9 @@ public:
     }
 };
 
-StoreServer* store_server_start(int port, int* bound_port) {
+StoreServer* store_server_start(int port, int* bound_port, bool loopback_only) {
     auto* s = new StoreServer();
-    s->listen_fd = tcp_listen(port, bound_port);
+    s->listen_fd = tcp_listen(port, bound_port, loopback_only);
     if (s->listen_fd < 0) {
         delete s;
         return nullptr;

@@ -27,13 +27,14 @@ private:
     int fd_ = -1;
 };
 
-StoreServer* store_server_start(int port, int* bound_port);  // port 0 = ephemeral
+// port 0 = ephemeral; loopback_only binds 127.0.0.1 instead of every interface
+StoreServer* store_server_start(int port, int* bound_port, bool loopback_only = false);
 void store_server_stop(StoreServer* s);
 
 // socket helpers shared with the data plane
 bool send_all(int fd, const void* buf, size_t n);
 bool recv_all(int fd, void* buf, size_t n, int timeout_ms = -1);
-int tcp_listen(int port, int* bound_port);
+int tcp_listen(int port, int* bound_port, bool loopback_only = false);
 int tcp_connect(const std::string& host, int port, int timeout_ms);
 int tcp_accept(int listen_fd, int timeout_ms);
 

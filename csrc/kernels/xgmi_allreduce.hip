@@ -47,30 +47,41 @@ __device__ __forceinline__ bool wait_flag(unsigned* p, unsigned epoch, long long
     return false;
 }
 
+// All payload traffic is system-coherent (sc0 sc1 = aux 17): loads miss every cache level that a
+// peer's store cannot reach, stores are written through - the data path does not depend on what a
+// fence does to lines the L2 believes to be local.  8 elements per lane and access.
+constexpr int AUX_SYS = 17;
+
 template <bool BF16>
-__device__ __forceinline__ void load8(const void* base, long long i8, float* v) {
+__device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t rs, long long i8, float* v) {
     if (BF16) {
-        bf16x8 x = *reinterpret_cast<const bf16x8*>((const bf16_t*)base + i8 * 8);
+        u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(i8 * 16), 0, AUX_SYS);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(x[e]);
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = __builtin_bit_cast(float, x[e] << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, x[e] & 0xffff0000u);
+        }
     } else {
-        f32x4 a = *reinterpret_cast<const f32x4*>((const float*)base + i8 * 8);
-        f32x4 b = *reinterpret_cast<const f32x4*>((const float*)base + i8 * 8 + 4);
+        const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(i8 * 32), 0, AUX_SYS));
+        const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(i8 * 32 + 16), 0, AUX_SYS));
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
     }
 }
 template <bool BF16>
-__device__ __forceinline__ void store8(void* base, long long i8, const float* v) {
+__device__ __forceinline__ void store8(__amdgpu_buffer_rsrc_t rs, long long i8, const float* v) {
     if (BF16) {
-        bf16x8 x;
+        u32x4 x;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = f2bf(v[e]);
-        *reinterpret_cast<bf16x8*>((bf16_t*)base + i8 * 8) = x;
+        for (int e = 0; e < 4; ++e) {
+            bf16x2 pr = {f2bf(v[2 * e]), f2bf(v[2 * e + 1])};
+            x[e] = __builtin_bit_cast(unsigned, pr);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(x, rs, (int)(i8 * 16), 0, AUX_SYS);
     } else {
-        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-        *reinterpret_cast<f32x4*>((float*)base + i8 * 8) = a;
-        *reinterpret_cast<f32x4*>((float*)base + i8 * 8 + 4) = b;
+        const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, a), rs, (int)(i8 * 32), 0, AUX_SYS);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, b), rs, (int)(i8 * 32 + 16), 0, AUX_SYS);
     }
 }
 
@@ -87,32 +98,53 @@ __global__ void __launch_bounds__(256) xgmi_allreduce_kernel(const XgmiParams p)
     // 2. wait until every rank has announced (poll my own flag page)
     if (threadIdx.x == 0) {
         bool ok = true;
-        for (int q = 0; q < n && ok; ++q) ok = wait_flag(p.flags[r] + q, p.epoch, p.spin_limit);
-        if (!ok) __hip_atomic_store(p.timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        int q = 0;
+        for (; q < n && ok; ++q) ok = wait_flag(p.flags[r] + q, p.epoch, p.spin_limit);
+        // timeout word = 0x100 | (peer + 1): the peer whose "ready" never arrived
+        if (!ok) __hip_atomic_store(p.timeout_word, 0x100u | (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ok_s = ok ? 1 : 0;
     }
     __syncthreads();
     if (!ok_s) return;  // uniform per block; peers time out on their own bounded spins
+    // Acquire AFTER the poll has matched, by every wave, and waited for: the invalidate completes
+    // asynchronously, a load issued before it has finished can still hit a stale line (the peers'
+    // buffers have the same addresses every step and this kernel may have been spinning since
+    // before they were written).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const long long total8 = p.count >> 3;
     const long long shard8 = p.one_shot ? total8 : total8 / n;
     const long long base8 = p.one_shot ? 0 : shard8 * r;
+    const int nbytes = (int)(p.count * (BF16 ? 2 : 4));   // < 2^31, checked by the launcher
+    __amdgpu_buffer_rsrc_t rs[MAX_RANKS];
+#pragma unroll
+    for (int q = 0; q < MAX_RANKS; ++q)
+        rs[q] = __builtin_amdgcn_make_buffer_rsrc(q < n ? p.bufs[q] : p.bufs[0], 0, q < n ? nbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.one_shot ? p.outs[r] : p.bufs[0], 0, nbytes, 0x00020000);
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < shard8; i += stride) {
-        float acc[8], v[8];
-        load8<BF16>(p.bufs[0], base8 + i, acc);
-        for (int q = 1; q < n; ++q) {
-            load8<BF16>(p.bufs[q], base8 + i, v);
+        // fixed summation order (rank 0, 1, ...): every rank computes bit-identical sums
+        float acc[8], v[MAX_RANKS][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v[e];
-        }
+        for (int q = 0; q < MAX_RANKS; ++q)
+            if (q < n) load8<BF16>(rs[q], base8 + i, v[q]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = v[0][e];
+#pragma unroll
+        for (int q = 1; q < MAX_RANKS; ++q)
+            if (q < n) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[q][e];
+            }
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] *= p.scale;
         if (p.one_shot) {
-            store8<BF16>(p.outs[r], i, acc);
+            store8<BF16>(ro, i, acc);
         } else {
-            for (int q = 0; q < n; ++q) store8<BF16>(p.bufs[(r + q) % n], base8 + i, acc);
+#pragma unroll
+            for (int q = 0; q < MAX_RANKS; ++q)
+                if (q < n) store8<BF16>(rs[q], base8 + i, acc);
         }
     }
     // 3. publish: every writing wave drains its stores, the last workgroup signals "done"
@@ -133,8 +165,10 @@ __global__ void __launch_bounds__(256) xgmi_allreduce_kernel(const XgmiParams p)
     //    (two-shot) / every rank has finished reading my buffer (one-shot)
     if (threadIdx.x == 0) {
         bool ok = true;
-        for (int q = 0; q < n && ok; ++q) ok = wait_flag(p.flags[r] + 8 + q, p.epoch, p.spin_limit);
-        if (!ok) __hip_atomic_store(p.timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        int q = 0;
+        for (; q < n && ok; ++q) ok = wait_flag(p.flags[r] + 8 + q, p.epoch, p.spin_limit);
+        // 0x200 | (peer + 1): the peer whose "done" never arrived
+        if (!ok) __hip_atomic_store(p.timeout_word, 0x200u | (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
 }
@@ -166,6 +200,7 @@ extern "C" int ddl_xgmi_allreduce(void* const* bufs, void* const* flags, void* c
                                   void* timeout_word, int blocks, int simulate, hipStream_t stream) {
     if (!bufs || !flags || !timeout_word || nranks < 1 || nranks > MAX_RANKS || rank < 0 || rank >= nranks) return DDL_EINVAL;
     if (count <= 0 || (count % (8LL * nranks)) != 0 || epoch == 0 || spin_limit <= 0) return DDL_EINVAL;
+    if (count * (is_bf16 ? 2 : 4) >= 0x7fffffffLL) return DDL_EINVAL;  // 32-bit buffer offsets
     if (one_shot && !outs) return DDL_EINVAL;
     if (blocks < 1 || blocks > 64) return DDL_EINVAL;  // small by design: always fully resident
     XgmiParams p;

@@ -127,6 +127,11 @@ def launch(command, np_total, hosts=None, exports=None, tag_output=True, timeout
     """Run ``command`` (argv list) as ``np_total`` ranks; returns the job's exit code."""
     hosts = hosts or [("localhost", np_total)]
     exports = dict(exports or {})
+    # per-job secret: the engine's control plane only unpickles objects signed with it
+    if "DDL_JOB_TOKEN" not in exports and "DDL_JOB_TOKEN" not in os.environ:
+        import secrets
+
+        exports["DDL_JOB_TOKEN"] = secrets.token_hex(16)
     sink = sink or sys.stdout
     placement = assign_slots(hosts, np_total)
     first_host = placement[0][1]

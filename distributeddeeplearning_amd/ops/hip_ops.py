@@ -169,6 +169,7 @@ def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho
 # returns None to autograd for them; listeners (DistributedOptimizer) are told which parameter
 # just became ready, which is what autograd's post-accumulate hook would have done.
 _grad_listeners = []
+_listener_params = {}   # id(listener) -> set of parameter ids it serves
 
 
 def add_grad_listener(fn):
@@ -179,6 +180,19 @@ def add_grad_listener(fn):
 def remove_grad_listener(fn):
     if fn in _grad_listeners:
         _grad_listeners.remove(fn)
+    _listener_params.pop(id(fn), None)
+
+
+def claim_grad_listener(fn, params):
+    """Register ``fn`` as THE listener for ``params`` (an iterable of ``id(parameter)``): an older
+    listener serving any of them (an optimizer that was re-wrapped or rebuilt over the same model)
+    is dropped - two optimizers must never both exchange one parameter's gradient."""
+    mine = set(params)
+    for old in list(_grad_listeners):
+        if _listener_params.get(id(old), set()) & mine:
+            remove_grad_listener(old)
+    add_grad_listener(fn)
+    _listener_params[id(fn)] = mine
 
 
 def _direct_grad_ok(p):
@@ -193,19 +207,23 @@ def _direct_grad_ok(p):
 _DEFER = {"on": False, "items": []}
 
 
+def _tell(p):
+    for fn in list(_grad_listeners):
+        if fn(p) is False:       # a listener whose optimizer is gone
+            remove_grad_listener(fn)
+
+
 def _notify(p):
     if _DEFER["on"]:
         _DEFER["items"].append(p)
         return
-    for fn in _grad_listeners:
-        fn(p)
+    _tell(p)
 
 
 def _flush_notifications():
     items, _DEFER["items"] = _DEFER["items"], []
     for p in items:
-        for fn in _grad_listeners:
-            fn(p)
+        _tell(p)
 
 
 # ---- raw (autograd-free) building blocks -------------------------------------------------------

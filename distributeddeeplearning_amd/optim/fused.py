@@ -24,7 +24,7 @@ from __future__ import annotations
 import torch
 from torch.optim import Optimizer
 
-from ..parallel.bucket import GradArena
+from ..parallel.bucket import GradArena, arena_options
 from ..utils.config import EngineConfig
 
 __all__ = ["FusedSGD", "FusedLARS", "default_weight_decay_filter"]
@@ -49,8 +49,7 @@ class _ArenaOptimizer(Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError("arena optimizers use a single parameter group")
         cfg = engine_config or EngineConfig.from_env()
-        self.arena = GradArena(named, cfg.first_bucket_bytes, cfg.fusion_threshold,
-                               flatten_params=True, tail_bucket_bytes=cfg.tail_bucket_bytes)
+        self.arena = GradArena(named, flatten_params=True, **arena_options(cfg))
         flt = weight_decay_filter or default_weight_decay_filter
         self._names = {id(p): n for n, p in named}
         self.momentum_buf = {}
@@ -225,31 +224,55 @@ class FusedSGD(_ArenaOptimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        g0 = self.param_groups[0]
-        lr, mu, wd, nesterov = g0["lr"], g0["momentum"], g0["weight_decay"], g0["nesterov"]
+        self.begin_step()
+        for run in self.runs:
+            self._update(run["dtype"], run["start"], run["end"], run["decay"])
+        self.end_step()
+        return loss
+
+    # -- bucket-wise stepping (DistributedOptimizer: update bucket k right after the stream has
+    #    waited for bucket k's all-reduce, while later buckets are still in flight) ------------
+    def begin_step(self):
         from ..ops import kernels
 
-        hip = self.arena.device.type == "cuda" and kernels.enabled()
+        self._hip = self.arena.device.type == "cuda" and kernels.enabled()
+
+    @torch.no_grad()
+    def step_bucket(self, dtype, start, end):
+        """Update the slice [start, end) of ``dtype``'s arenas (any range: it is intersected with
+        the hyper-parameter runs)."""
         for run in self.runs:
-            dt, a, b = run["dtype"], run["start"], run["end"]
-            run_wd = wd if run["decay"] else 0.0
-            grads = self.arena.grads[dt][a:b]
-            w = self._weights(dt)[a:b]
-            v = self.momentum_buf[dt][a:b]
-            if hip:
-                lowp = self.arena.params[dt][a:b] if dt in self.master else None
-                klr, kscale = self._kernel_lr(lr)
-                kernels.fused_sgd_(w, grads, v, lowp, klr, mu, run_wd, nesterov, kscale)
+            if run["dtype"] != dtype:
                 continue
-            g = grads.to(torch.float32)
-            if run_wd:
-                g = g.add(w, alpha=run_wd)
-            v.mul_(mu).add_(g)
-            w.add_(g.add(v, alpha=mu) if nesterov else v, alpha=-lr)
-            self._publish(dt, a, b)
+            a, b = max(start, run["start"]), min(end, run["end"])
+            if a < b:
+                self._update(dtype, a, b, run["decay"])
+
+    def end_step(self):
         self._step += 1
-        self._notify_weights_changed(hip)
-        return loss
+        self._notify_weights_changed(self._hip)
+        return None
+
+    def _update(self, dt, a, b, decay):
+        g0 = self.param_groups[0]
+        lr, mu, wd, nesterov = g0["lr"], g0["momentum"], g0["weight_decay"], g0["nesterov"]
+        run_wd = wd if decay else 0.0
+        grads = self.arena.grads[dt][a:b]
+        w = self._weights(dt)[a:b]
+        v = self.momentum_buf[dt][a:b]
+        if self._hip:
+            from ..ops import kernels
+
+            lowp = self.arena.params[dt][a:b] if dt in self.master else None
+            klr, kscale = self._kernel_lr(lr)
+            kernels.fused_sgd_(w, grads, v, lowp, klr, mu, run_wd, nesterov, kscale)
+            return
+        g = grads.to(torch.float32)
+        if run_wd:
+            g = g.add(w, alpha=run_wd)
+        v.mul_(mu).add_(g)
+        w.add_(g.add(v, alpha=mu) if nesterov else v, alpha=-lr)
+        self._publish(dt, a, b)
 
 
 class FusedLARS(_ArenaOptimizer):

@@ -100,19 +100,27 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
 
                 _S.cpu_affinity = bind_to_gpu_numa(_S.local_rank % n_dev)
 
-        engine = (cfg.engine or "torch").lower()
-        if engine not in ("torch", "native"):
-            raise ValueError("unknown HVD_ENGINE %r (expected torch|native)" % engine)
+        engine = (cfg.engine or "auto").lower()
+        if engine not in ("auto", "torch", "native"):
+            raise ValueError("unknown HVD_ENGINE %r (expected auto|torch|native)" % engine)
+        if engine == "auto":
+            # GPUs: the in-tree engine (own comm thread, RCCL called directly, watchdog) IS the data
+            # plane; the c10d process group stays available as HVD_ENGINE=torch.  CPU/gloo jobs keep
+            # torch.distributed's gloo (the native engine's TCP ring is opt-in there).
+            from ..ops import native as _native
+
+            engine = "native" if (want == "rccl" and _native.engine_lib() is not None) else "torch"
         _S.engine = engine
         force = bool(cfg.force_collectives)
-        if world > 1 and engine == "native":
+        if (world > 1 or force) and engine == "native":
             from .comm import NativeComm
 
             _S.comm = NativeComm(rk, world, _S.local_rank,
                                  os.environ.get("MASTER_ADDR", "127.0.0.1"),
                                  int(os.environ.get("MASTER_PORT", "29500")),
                                  timeout_s or cfg.collective_timeout_s, cfg.stall_warning_s,
-                                 use_rccl=(want == "rccl"), timeline=cfg.timeline)
+                                 use_rccl=(want == "rccl"), timeline=cfg.timeline,
+                                 allreduce_algo=cfg.allreduce_algo)
             _S.backend = want
         elif world > 1 or force:
             if dist.is_initialized():

@@ -21,8 +21,13 @@ bucket ends to 8 shards × 256 B so that reduce-scatter style kernels can split 
 across 8 peers with 16-byte vector accesses.
 
 The planner itself is pure Python over ``(name, numel, dtype)`` records and has a native twin
-(``csrc/engine/bucket_plan.cpp``) used when the engine library is built; both are covered by
-the same unit test.
+(``ddl_bucket_plan`` in ``csrc/engine/engine.cpp``); ``tests/test_native_engine.py`` checks that
+both produce the same plan for ResNet-50.
+
+``HVD_COMM_DTYPE=fp32`` (``grad_dtype``) keeps the gradient arenas in fp32 whatever the parameter
+dtype: the split-K weight-gradient reduce writes fp32 directly, the collective reduces fp32 on the
+wire and multi-pass accumulation (``backward_passes_per_step > 1``) happens in fp32.  Offsets are
+shared between the parameter, gradient, momentum and master arenas of one parameter dtype.
 """
 from __future__ import annotations
 
@@ -32,7 +37,7 @@ from typing import Iterable, Sequence
 import torch
 
 __all__ = ["Segment", "Bucket", "ArenaPlan", "plan_arenas", "GradArena", "SEG_ALIGN_BYTES",
-           "BUCKET_ALIGN_BYTES"]
+           "BUCKET_ALIGN_BYTES", "arena_options"]
 
 SEG_ALIGN_BYTES = 256
 BUCKET_ALIGN_BYTES = 8 * 256
@@ -72,7 +77,8 @@ class ArenaPlan:
 
 
 def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_bytes: int,
-                reverse: bool = True, tail_bucket_bytes: int = 0) -> dict:
+                reverse: bool = True, tail_bucket_bytes: int = 0, num_buckets: int = 0,
+                wire_esize: dict | None = None) -> dict:
     """Plan one arena per dtype.
 
     ``entries`` is a sequence of ``(name, shape, dtype)`` in registration (forward) order.
@@ -83,6 +89,10 @@ def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_by
     arena: those tensors (the first layers) only become ready at the very end of backward, and
     whatever shares their bucket cannot be exchanged before — with a small tail bucket the large
     one in front of it overlaps with the stem's backward instead of waiting for it.
+
+    ``num_buckets`` > 0 (``HVD_NUM_BUCKETS``) replaces the byte caps: every arena is cut into that
+    many buckets of about equal size.  ``wire_esize`` maps a dtype to the element size the byte
+    caps refer to when the gradients travel in another dtype than the parameters.
     """
     by_dtype: dict = {}
     order = list(enumerate(entries))
@@ -95,6 +105,7 @@ def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_by
         esize = torch.empty((), dtype=dtype).element_size()
         seg_align = max(SEG_ALIGN_BYTES // esize, 1)
         bkt_align = max(BUCKET_ALIGN_BYTES // esize, 1)
+        esize = (wire_esize or {}).get(dtype, esize)   # caps are in bytes on the wire
         segments, buckets = [], []
         cursor = 0
         cur = Bucket(0, 0, 0)
@@ -105,6 +116,10 @@ def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_by
             for d in shape:
                 sz *= int(d)
             sizes.append(sz)
+        first_cap, later_cap = first_bucket_bytes, bucket_cap_bytes
+        if num_buckets > 0:
+            first_cap = later_cap = max((sum(sizes) + num_buckets - 1) // num_buckets, 1)
+            tail_bucket_bytes = 0
         if tail_bucket_bytes > 0 and sum(sizes) > 4 * tail_bucket_bytes:
             acc = 0
             for pos in range(len(items) - 1, 0, -1):
@@ -116,7 +131,7 @@ def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_by
             n = 1
             for d in shape:
                 n *= int(d)
-            cap = first_bucket_bytes if not buckets else bucket_cap_bytes
+            cap = first_cap if not buckets else later_cap
             used_bytes = (cursor - cur.start) * esize
             if cur.segments and (used_bytes + n * esize > cap or pos == tail_start):
                 cursor = _round_up(cursor, bkt_align)
@@ -133,6 +148,17 @@ def plan_arenas(entries: Sequence[tuple], first_bucket_bytes: int, bucket_cap_by
             buckets.append(cur)
         plans[dtype] = ArenaPlan(dtype, cursor, segments, buckets)
     return plans
+
+
+def arena_options(cfg) -> dict:
+    """GradArena keyword arguments from an ``EngineConfig`` (HVD_FIRST_BUCKET_BYTES,
+    HVD_FUSION_THRESHOLD, HVD_TAIL_BUCKET_BYTES, HVD_NUM_BUCKETS, HVD_COMM_DTYPE)."""
+    comm = (cfg.comm_dtype or "auto").lower()
+    if comm not in ("auto", "bf16", "fp32", "float32", "bfloat16"):
+        raise ValueError("unknown HVD_COMM_DTYPE %r (expected auto|bf16|fp32)" % cfg.comm_dtype)
+    return {"first_bucket_bytes": cfg.first_bucket_bytes, "bucket_cap_bytes": cfg.fusion_threshold,
+            "tail_bucket_bytes": cfg.tail_bucket_bytes, "num_buckets": cfg.num_buckets,
+            "grad_dtype": torch.float32 if comm in ("fp32", "float32") else None}
 
 
 def _shaped_view(flat: torch.Tensor, seg: Segment, like: torch.Tensor) -> torch.Tensor:
@@ -155,7 +181,8 @@ class GradArena:
     """
 
     def __init__(self, named_params: Iterable, first_bucket_bytes: int, bucket_cap_bytes: int,
-                 flatten_params: bool = False, grad_dtype=None, tail_bucket_bytes: int = 0):
+                 flatten_params: bool = False, grad_dtype=None, tail_bucket_bytes: int = 0,
+                 num_buckets: int = 0):
         named = [(n, p) for n, p in named_params if p.requires_grad]
         if not named:
             raise ValueError("no trainable parameters")
@@ -168,11 +195,15 @@ class GradArena:
             raise ValueError("all parameters must live on one device, got %s" % devices)
         self.device = devices.pop()
         self.named = named
-        gdt = (lambda p: grad_dtype or p.dtype)
-        self.plans = plan_arenas([(n, p.shape, gdt(p)) for n, p in named],
+        # arenas are keyed by PARAMETER dtype (parameter, gradient, momentum and master arenas of
+        # one key share their offsets); the gradient arena's own dtype may differ (grad_dtype)
+        self.grad_dtype = {p.dtype: (grad_dtype or p.dtype) for _, p in named}
+        wire = {dt: torch.empty((), dtype=g).element_size() for dt, g in self.grad_dtype.items()}
+        self.plans = plan_arenas([(n, p.shape, p.dtype) for n, p in named],
                                  first_bucket_bytes, bucket_cap_bytes,
-                                 tail_bucket_bytes=tail_bucket_bytes)
-        self.grads = {dt: torch.zeros(pl.numel, dtype=dt, device=self.device)
+                                 tail_bucket_bytes=tail_bucket_bytes, num_buckets=num_buckets,
+                                 wire_esize=wire)
+        self.grads = {dt: torch.zeros(pl.numel, dtype=self.grad_dtype[dt], device=self.device)
                       for dt, pl in self.plans.items()}
         self.params = {}
         self.param_of_segment = {}
@@ -227,7 +258,9 @@ class GradArena:
         for dt, plan in self.plans.items():
             for b in plan.buckets:
                 esz = self.grads[dt].element_size()
-                lines.append("%s bucket %d: %d tensors, %.2f MiB" % (
+                wire = "" if self.grads[dt].dtype == dt else \
+                    " as %s" % str(self.grads[dt].dtype).replace("torch.", "")
+                lines.append("%s bucket %d: %d tensors, %.2f MiB%s" % (
                     str(dt).replace("torch.", ""), b.index, len(b.segments),
-                    b.numel * esz / 2 ** 20))
+                    b.numel * esz / 2 ** 20, wire))
         return "\n".join(lines)

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import ctypes
 import datetime
+import hashlib
+import hmac
 import itertools
 import os
 import pickle
@@ -120,6 +122,12 @@ class TorchComm:
 _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.bfloat16: 3, torch.int32: 4,
            torch.uint8: 5, torch.float16: 6}
 _OPS = {"sum": 0, "average": 1, "min": 2, "max": 3}
+_ALGOS = {"rccl": 0, "twoshot": 1, "oneshot": 2}
+# HVD_ALLREDUCE_ALGO=auto: buckets up to this size go through the one-shot kernel (latency-bound:
+# one hop instead of RCCL's ring/tree steps), up to _AUTO_TWOSHOT_MAX through two-shot (all seven
+# xGMI links busy, 2 x S/8 per link), larger ones through RCCL
+ONE_SHOT_MAX_BYTES = 512 * 1024
+_AUTO_TWOSHOT_MAX = 64 * 1024 * 1024
 
 
 class _HostWork(Work):
@@ -145,6 +153,11 @@ class _HostWork(Work):
 
 
 class _DeviceWork(Work):
+    """A device collective launched by the engine's communication thread.  ``wait`` orders the
+    current HIP stream after it (the host blocks only until the comm thread has issued the
+    launch, microseconds); a collective that the watchdog declared dead (``HVD_COLLECTIVE_
+    TIMEOUT_S``) raises here."""
+
     def __init__(self, comm, handle, keep):
         self.comm, self.handle, self.keep = comm, handle, keep
         self.done = False
@@ -152,13 +165,58 @@ class _DeviceWork(Work):
     def wait(self, timeout_s=None):
         if not self.done:
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if self.comm.lib.ddl_rccl_wait_stream(ctypes.c_longlong(self.handle), stream) != 0:
-                raise CommError("unknown RCCL handle")
+            rc = self.comm.lib.ddl_eng_device_wait(ctypes.c_longlong(self.handle), stream,
+                                                   ctypes.c_double(timeout_s or self.comm.timeout_s))
+            if rc == 1:
+                return False
+            if rc != 0:
+                raise CommError("device collective failed: %s" % self.comm.last_error())
+            self.done = True
+        return True
+
+    def wait_host(self, timeout_s=None):
+        """Block the HOST until the collective has completed on the device."""
+        if not self.done:
+            rc = self.comm.lib.ddl_eng_device_wait_host(ctypes.c_longlong(self.handle),
+                                                        ctypes.c_double(timeout_s or self.comm.timeout_s))
+            if rc == 1:
+                return False
+            if rc != 0:
+                raise CommError("device collective failed: %s" % self.comm.last_error())
             self.done = True
         return True
 
     def is_completed(self):
-        return self.done or self.comm.lib.ddl_rccl_poll(ctypes.c_longlong(self.handle)) == 1
+        return self.done or self.comm.lib.ddl_eng_poll(ctypes.c_longlong(self.handle)) >= 2
+
+
+def engine_port(rank, master_addr, master_port, timeout_s=300.0):
+    """Control port of the native engine's TCP store.
+
+    ``DDL_ENGINE_PORT`` wins.  Under ``torch.distributed.run`` the agent already hosts a store on
+    MASTER_PORT: rank 0 then takes any free port and publishes it there (a port "next to"
+    MASTER_PORT may be taken on a busy host).  Otherwise - our own launcher, ``mpirun`` - the
+    engine listens on MASTER_PORT + 1."""
+    explicit = os.environ.get("DDL_ENGINE_PORT")
+    if explicit:
+        return int(explicit)
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true":
+        try:
+            store = dist.TCPStore(master_addr, int(master_port), is_master=False,
+                                  timeout=datetime.timedelta(seconds=timeout_s))
+            key = "ddl/engine_port/%s" % os.environ.get("TORCHELASTIC_RUN_ID", "0")
+            if rank == 0:
+                import socket
+
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1" if master_addr in ("127.0.0.1", "localhost") else "", 0))
+                    port = sk.getsockname()[1]
+                store.set(key, str(port))
+                return port
+            return int(store.get(key).decode())
+        except Exception:  # agent store unreachable: fall back to the fixed rule
+            pass
+    return int(master_port) + 1
 
 
 class NativeComm:
@@ -166,7 +224,7 @@ class NativeComm:
     checks_consistency = True  # every engine message carries a verified (op, dtype, count, name) header
 
     def __init__(self, rank, size, local_rank, master_addr, master_port, timeout_s=300.0,
-                 stall_warning_s=60.0, use_rccl=False, timeline=None):
+                 stall_warning_s=60.0, use_rccl=False, timeline=None, allreduce_algo="rccl"):
         lib = _native.engine_lib()
         if lib is None:
             raise CommError("native engine library is not built (run `python build.py`)")
@@ -174,28 +232,84 @@ class NativeComm:
         lib.ddl_eng_last_error.restype = ctypes.c_char_p
         lib.ddl_rccl_last_error.restype = ctypes.c_char_p
         lib.ddl_eng_store_data.restype = ctypes.c_void_p
+        lib.ddl_rccl_stream.restype = ctypes.c_void_p
         for fn in ("ddl_eng_allreduce_async", "ddl_eng_broadcast_async", "ddl_eng_allgather_async",
                    "ddl_eng_barrier_async", "ddl_eng_store_get", "ddl_eng_store_add",
-                   "ddl_rccl_allreduce", "ddl_rccl_broadcast", "ddl_rccl_allgather"):
+                   "ddl_eng_device_collective", "ddl_eng_stats", "ddl_rccl_launch_count",
+                   "ddl_xgmi_launch_count"):
             getattr(lib, fn).restype = ctypes.c_longlong
+        lib.ddl_eng_device_collective.argtypes = [
+            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p]
+        lib.ddl_eng_device_wait.argtypes = [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_double]
+        lib.ddl_eng_device_wait_host.argtypes = [ctypes.c_longlong, ctypes.c_double]
         self.rank, self.size, self.timeout_s = rank, size, float(timeout_s)
-        # the engine's control port sits next to the launcher's MASTER_PORT
-        port = int(master_port) + 1
+        port = engine_port(rank, master_addr, master_port, timeout_s)
         rc = lib.ddl_eng_init(rank, size, master_addr.encode(), port, ctypes.c_double(timeout_s),
                               ctypes.c_double(stall_warning_s))
         if rc != 0:
             raise CommError("engine init failed: %s" % self.last_error())
         self.rccl = False
+        self.has_rccl_comm = False
+        self.algo = "rccl"
+        self._regions = []
+        # broadcast_object blobs are authenticated with a per-job secret when the launcher
+        # provides one (DDL_JOB_TOKEN): nothing unauthenticated is ever unpickled
+        self._token = (os.environ.get("DDL_JOB_TOKEN") or "").encode()
         if use_rccl:
             dev = torch.cuda.current_device()
             if lib.ddl_rccl_init(rank, size, dev, int(timeout_s * 1000)) != 0:
                 raise CommError("RCCL init failed: %s" % lib.ddl_rccl_last_error().decode())
             self.rccl = True
+            # DDL_RCCL_SKIP_COMM=1 (several ranks on ONE GPU, which RCCL refuses): the device plane
+            # has no communicator; whatever the xGMI kernel cannot serve is staged through the host
+            self.has_rccl_comm = bool(lib.ddl_rccl_has_comm())
+            self._init_algo(allreduce_algo)
         if timeline:
             lib.ddl_eng_timeline_start(("%s.engine.%d.json" % (timeline, rank)).encode())
         self._seq = itertools.count()
 
     backend = "native"
+
+    def _init_algo(self, algo):
+        algo = (algo or "rccl").lower()
+        if algo not in ("rccl", "twoshot", "oneshot", "auto"):
+            raise CommError("unknown HVD_ALLREDUCE_ALGO %r (expected rccl|twoshot|oneshot|auto)" % algo)
+        if algo == "rccl" or self.size == 1:
+            return
+        if self.size > 8:
+            raise CommError("HVD_ALLREDUCE_ALGO=%s spans one node of at most 8 GPUs" % algo)
+        from ..ops import kernels as _k
+
+        fn = ctypes.cast(_k.lib().ddl_xgmi_allreduce, ctypes.c_void_p)
+        blocks = int(os.environ.get("HVD_XGMI_BLOCKS", "16"))
+        spins = int(os.environ.get("HVD_XGMI_SPIN_LIMIT", "20000000"))
+        if self.lib.ddl_xgmi_init(fn, blocks, ctypes.c_longlong(spins)) != 0:
+            raise CommError("xGMI plane init failed: %s" % self.lib.ddl_rccl_last_error().decode())
+        self.algo = algo
+
+    def register_region(self, tensor):
+        """Collective: make ``tensor``'s memory (a gradient arena) reachable by the direct xGMI
+        all-reduce on every rank.  No-op unless HVD_ALLREDUCE_ALGO selects that kernel."""
+        if self.algo == "rccl" or not tensor.is_cuda:
+            return -1
+        nbytes = tensor.numel() * tensor.element_size()
+        rid = self.lib.ddl_xgmi_register(ctypes.c_void_p(tensor.data_ptr()), ctypes.c_longlong(nbytes))
+        if rid < 0:
+            raise CommError("xGMI region registration failed: %s" % self.lib.ddl_rccl_last_error().decode())
+        self._regions.append(tensor)  # keep the storage alive as long as peers map it
+        return rid
+
+    def _pick_algo(self, tensor, op):
+        if self.algo == "rccl" or op not in ("sum", "average") or \
+                tensor.dtype not in (torch.float32, torch.bfloat16):
+            return 0
+        if self.algo != "auto":
+            return _ALGOS[self.algo]
+        nbytes = tensor.numel() * tensor.element_size()
+        if nbytes <= ONE_SHOT_MAX_BYTES:
+            return 2
+        return 1 if nbytes <= _AUTO_TWOSHOT_MAX else 0
 
     @property
     def supports_avg(self):
@@ -213,66 +327,119 @@ class NativeComm:
     def _name(self, name):
         return (name or "noname").encode()
 
+    def _device(self, kind, tensor, out, n, dt, redop, root, algo, name, keep):
+        if not self.rccl:
+            raise CommError("device tensor given but the engine was started without RCCL")
+        if not self.has_rccl_comm and not (kind == 0 and algo != 0 and self._registered(tensor)):
+            return self._staged(kind, tensor, out, n, dt, redop, root, name)
+        h = self.lib.ddl_eng_device_collective(kind, tensor.data_ptr(), None if out is None else out.data_ptr(),
+                                               n, dt, redop, root, algo,
+                                               torch.cuda.current_stream().cuda_stream, self._name(name))
+        if h < 0:
+            raise CommError(self.last_error())
+        return _DeviceWork(self, h, keep)
+
+    def _registered(self, t):
+        a, b = t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()
+        return any(r.data_ptr() <= a and b <= r.data_ptr() + r.numel() * r.element_size()
+                   for r in self._regions) and t.numel() % (8 * self.size) == 0
+
+    def _staged(self, kind, tensor, out, n, dt, redop, root, name):
+        """Device tensor through the host TCP ring (communicator-less test mode only)."""
+        host = tensor.detach().cpu()
+        if kind == 0:
+            h = self.lib.ddl_eng_allreduce_async(ctypes.c_void_p(host.data_ptr()), ctypes.c_longlong(n), dt,
+                                                 redop, self._name(name))
+        elif kind == 1:
+            h = self.lib.ddl_eng_broadcast_async(ctypes.c_void_p(host.data_ptr()), ctypes.c_longlong(n), dt,
+                                                 root, self._name(name))
+        else:
+            hout = torch.empty(out.shape, dtype=out.dtype)
+            h = self.lib.ddl_eng_allgather_async(ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(hout.data_ptr()),
+                                                 ctypes.c_longlong(n), dt, self._name(name))
+        if not _HostWork(self, h, host).wait(self.timeout_s):
+            raise CommError("staged collective timed out")
+        if kind == 2:
+            out.copy_(hout)
+        else:
+            tensor.copy_(host)
+        return _DoneWork()
+
     def all_reduce(self, tensor, op, name=None):
         self._check(tensor)
-        if self.size == 1:
-            return _DoneWork()
-        n, dt, p = tensor.numel(), _DTYPES[tensor.dtype], ctypes.c_void_p(tensor.data_ptr())
+        n, dt = tensor.numel(), _DTYPES[tensor.dtype]
         if tensor.is_cuda:
-            if not self.rccl:
-                raise CommError("device tensor given but the engine was started without RCCL")
-            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            h = self.lib.ddl_rccl_allreduce(p, ctypes.c_longlong(n), dt, _OPS[op], s, self._name(name))
-            if h < 0:
-                raise CommError(self.lib.ddl_rccl_last_error().decode())
-            return _DeviceWork(self, h, tensor)
-        h = self.lib.ddl_eng_allreduce_async(p, ctypes.c_longlong(n), dt, _OPS[op], self._name(name))
+            return self._device(0, tensor, None, n, dt, _OPS[op], 0, self._pick_algo(tensor, op), name, tensor)
+        h = self.lib.ddl_eng_allreduce_async(ctypes.c_void_p(tensor.data_ptr()), ctypes.c_longlong(n), dt,
+                                             _OPS[op], self._name(name))
         return _HostWork(self, h, tensor)
 
     def broadcast(self, tensor, root, name=None):
         self._check(tensor)
-        if self.size == 1:
-            return _DoneWork()
-        n, dt, p = tensor.numel(), _DTYPES[tensor.dtype], ctypes.c_void_p(tensor.data_ptr())
+        n, dt = tensor.numel(), _DTYPES[tensor.dtype]
         if tensor.is_cuda:
-            if not self.rccl:
-                raise CommError("device tensor given but the engine was started without RCCL")
-            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            h = self.lib.ddl_rccl_broadcast(p, ctypes.c_longlong(n), dt, root, s, self._name(name))
-            if h < 0:
-                raise CommError(self.lib.ddl_rccl_last_error().decode())
-            return _DeviceWork(self, h, tensor)
-        h = self.lib.ddl_eng_broadcast_async(p, ctypes.c_longlong(n), dt, root, self._name(name))
+            return self._device(1, tensor, None, n, dt, 0, root, 0, name, tensor)
+        h = self.lib.ddl_eng_broadcast_async(ctypes.c_void_p(tensor.data_ptr()), ctypes.c_longlong(n), dt,
+                                             root, self._name(name))
         return _HostWork(self, h, tensor)
 
     def all_gather_into(self, out, tensor, name=None):
         self._check(tensor)
         self._check(out)
         n, dt = tensor.numel(), _DTYPES[tensor.dtype]
-        pi, po = ctypes.c_void_p(tensor.data_ptr()), ctypes.c_void_p(out.data_ptr())
         if tensor.is_cuda:
-            if not self.rccl:
-                raise CommError("device tensor given but the engine was started without RCCL")
-            s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            h = self.lib.ddl_rccl_allgather(pi, po, ctypes.c_longlong(n), dt, s, self._name(name))
-            if h < 0:
-                raise CommError(self.lib.ddl_rccl_last_error().decode())
-            return _DeviceWork(self, h, (tensor, out))
-        h = self.lib.ddl_eng_allgather_async(pi, po, ctypes.c_longlong(n), dt, self._name(name))
+            return self._device(2, tensor, out, n, dt, 0, 0, 0, name, (tensor, out))
+        h = self.lib.ddl_eng_allgather_async(ctypes.c_void_p(tensor.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                             ctypes.c_longlong(n), dt, self._name(name))
         return _HostWork(self, h, (tensor, out))
 
     def barrier(self):
-        if self.size == 1:
-            return
         h = self.lib.ddl_eng_barrier_async(b"barrier")
         if not _HostWork(self, h, None).wait(self.timeout_s):
             raise CommError("barrier timed out")
         if self.rccl:
             torch.cuda.current_stream().synchronize()
 
+    def failed(self):
+        return bool(self.lib.ddl_eng_failed())
+
+    def stats(self):
+        """{collective name: {"count", "last_ms", "mean_ms", "algo", "bytes"}}: DEVICE time of every
+        named device collective, measured by the engine from HIP events."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        n = self.lib.ddl_eng_stats(buf, ctypes.c_longlong(len(buf)))
+        out = {}
+        if n <= 0:
+            return out
+        algos = {v: k for k, v in _ALGOS.items()}
+        for line in buf.value.decode().splitlines():
+            parts = line.rsplit(" ", 5)
+            if len(parts) == 6:
+                out[parts[0]] = {"count": int(parts[1]), "last_ms": float(parts[2]), "mean_ms": float(parts[3]),
+                                 "algo": algos.get(int(parts[4]), "?"), "bytes": int(parts[5])}
+        return out
+
+    def launch_counts(self):
+        return {"rccl": int(self.lib.ddl_rccl_launch_count()), "xgmi": int(self.lib.ddl_xgmi_launch_count())}
+
     # -- objects through the key-value store --------------------------------------------------
+    def _seal(self, blob):
+        if not self._token:
+            return b"\x00" + blob
+        return b"\x01" + hmac.new(self._token, blob, hashlib.sha256).digest() + blob
+
+    def _unseal(self, data):
+        if data[:1] == b"\x01":
+            mac, blob = data[1:33], data[33:]
+            if not self._token or not hmac.compare_digest(mac, hmac.new(self._token, blob, hashlib.sha256).digest()):
+                raise CommError("control-plane object failed authentication (DDL_JOB_TOKEN mismatch)")
+            return blob
+        if self._token:
+            raise CommError("unauthenticated control-plane object refused (this job runs with DDL_JOB_TOKEN)")
+        return data[1:]
+
     def _put(self, key, obj):
-        blob = pickle.dumps(obj)
+        blob = self._seal(pickle.dumps(obj))
         if self.lib.ddl_eng_store_set(key.encode(), blob, ctypes.c_longlong(len(blob))) != 0:
             raise CommError("store set failed")
 
@@ -280,7 +447,15 @@ class NativeComm:
         n = self.lib.ddl_eng_store_get(key.encode(), int(self.timeout_s * 1000))
         if n < 0:
             raise CommError("store get(%s) timed out" % key)
-        return pickle.loads(ctypes.string_at(self.lib.ddl_eng_store_data(), n))
+        return pickle.loads(self._unseal(ctypes.string_at(self.lib.ddl_eng_store_data(), n)))
+
+    def _ack(self, key, readers, keys):
+        """The last of ``readers`` readers deletes ``keys`` (the store does not grow with the job)."""
+        if readers <= 0:
+            return
+        if self.lib.ddl_eng_store_add((key + "/acks").encode(), ctypes.c_longlong(1)) == readers:
+            for k in list(keys) + [key + "/acks"]:
+                self.lib.ddl_eng_store_del(k.encode())
 
     def broadcast_object(self, obj, root, rank):
         if self.size == 1:
@@ -289,16 +464,22 @@ class NativeComm:
         if rank == root:
             self._put(key, obj)
             return obj
-        return self._get(key)
+        out = self._get(key)
+        self._ack(key, self.size - 1, [key])
+        return out
 
     def all_gather_object(self, obj, world):
         if self.size == 1:
             return [obj]
         seq = next(self._seq)
-        self._put("gobj/%d/%d" % (seq, self.rank), obj)
-        return [self._get("gobj/%d/%d" % (seq, r)) for r in range(world)]
+        keys = ["gobj/%d/%d" % (seq, r) for r in range(world)]
+        self._put(keys[self.rank], obj)
+        out = [self._get(k) for k in keys]
+        self._ack("gobj/%d" % seq, world, keys)
+        return out
 
     def shutdown(self):
         if self.rccl:
             self.lib.ddl_rccl_shutdown()
         self.lib.ddl_eng_shutdown()
+        self._regions = []

@@ -14,8 +14,13 @@ What differs from Horovod's design (MI355X-first):
 * ``param.grad`` are views into the arena: nothing is packed or unpacked;
 * averaging is fused into the reduction (``ncclAvg``);
 * ``step()`` orders the compute stream after the collectives with event waits — the host
-  never blocks — and a fused optimizer (``optim.FusedSGD``/``FusedLARS``) is updated bucket by
-  bucket so the update of early buckets overlaps the tail of the exchange;
+  never blocks.  With ``optim.FusedSGD`` the update runs bucket by bucket: the stream waits for
+  bucket k, updates bucket k's slice of the arenas, then waits for bucket k+1 — the update of
+  the early buckets overlaps the tail of the exchange (``FusedLARS`` needs every norm first and
+  updates after the last bucket);
+* per step the exposed communication time (how long the compute stream actually sat in those
+  waits, from HIP events) and the device time of every bucket's collective (from the engine)
+  are available through ``comm_metrics()`` and land in ``metrics.jsonl``;
 * the first backward records the actual hook order; a mismatch with the plan is reported in
   debug mode (``HVD_DEBUG=1``) together with a cross-rank plan hash check.
 """
@@ -28,7 +33,7 @@ import torch
 
 from . import backend as _b
 from . import timeline as _tl
-from .bucket import GradArena
+from .bucket import GradArena, arena_options
 from .compression import Compression
 
 __all__ = ["DistributedOptimizer"]
@@ -51,6 +56,69 @@ def _grad_exchange_context():
         return _hip_ops.grad_exchange_context()
     except Exception:  # pragma: no cover - ops layer unavailable
         return _NullContext()
+
+
+class _WeakListener:
+    """Readiness callback registered with ``ops.hip_ops``; dies with its optimizer."""
+
+    def __init__(self, opt):
+        import weakref
+
+        self.ref = weakref.ref(opt)
+
+    def __call__(self, p):
+        opt = self.ref()
+        if opt is None:
+            return False  # tells hip_ops to drop this listener
+        opt._ddl_on_direct_grad(p)
+        return True
+
+
+class _CommMetrics:
+    """Exposed communication time per step from HIP events around the stream waits of
+    ``synchronize()``; read one step late so that nothing ever synchronises with the device."""
+
+    def __init__(self):
+        self.pairs = []        # events recorded this step
+        self.prev = []         # last step's pairs (complete by the time the next step waits)
+        self.pool = []
+        self.last_exposed_ms = None
+        self.total_exposed_ms = 0.0
+        self.steps = 0
+
+    def _event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+
+    def before_wait(self):
+        if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+            return None
+        e = self._event()
+        e.record()
+        return e
+
+    def after_wait(self, e0):
+        if e0 is None:
+            return
+        e1 = self._event()
+        e1.record()
+        self.pairs.append((e0, e1))
+
+    def end_step(self):
+        # harvest the PREVIOUS step's events (long finished), then rotate
+        if self.prev and all(b.query() for _, b in self.prev):
+            ms = sum(a.elapsed_time(b) for a, b in self.prev)
+            self.last_exposed_ms = ms
+            self.total_exposed_ms += ms
+            self.steps += 1
+            for a, b in self.prev:
+                self.pool += [a, b]
+            self.prev = []
+        if not self.prev:
+            self.prev, self.pairs = self.pairs, []
+        else:  # still running (host far ahead): drop this step's sample rather than wait
+            for a, b in self.pairs:
+                self.pool += [a, b]
+            self.pairs = []
 
 
 class _BucketState:
@@ -94,12 +162,12 @@ class _DistributedMixin:
         self._ddl_step_count = 0
         self._ddl_order_seen = []
         self._ddl_order_checked = False
+        self._ddl_direct_seen = set()
         self._ddl_fault = _parse_fault(cfg.fault_inject)
         if arena is None:
             arena = getattr(self, "arena", None)  # fused optimizers bring their own arena
         if arena is None:
-            arena = GradArena(named, cfg.first_bucket_bytes, cfg.fusion_threshold,
-                              tail_bucket_bytes=cfg.tail_bucket_bytes)
+            arena = GradArena(named, **arena_options(cfg))
         self._ddl_arena = arena
         self._ddl_buckets = [_BucketState(dt, b, arena.bucket_tensor(dt, b), self._ddl_passes)
                              for dt, b in arena.all_buckets()]
@@ -110,14 +178,24 @@ class _DistributedMixin:
             if p.requires_grad:
                 self._ddl_hooks.append(p.register_post_accumulate_grad_hook(self._ddl_on_grad))
         # fused HIP blocks write gradients straight into the arena and report readiness here
-        # instead of through autograd's accumulate hook
+        # instead of through autograd's accumulate hook.  The listener holds this optimizer
+        # weakly: a dropped or re-wrapped optimizer must not keep receiving notifications (it
+        # would re-point param.grad at its stale arena and launch unmatched collectives).
         try:
             from ..ops import hip_ops as _hip_ops
 
-            _hip_ops.add_grad_listener(self._ddl_on_direct_grad)
+            self._ddl_listener = _WeakListener(self)
+            _hip_ops.claim_grad_listener(self._ddl_listener, self._ddl_names)
             _hip_ops.set_direct_grads(True)
         except Exception:  # pragma: no cover - ops layer unavailable
-            pass
+            self._ddl_listener = None
+        # HVD_ALLREDUCE_ALGO=twoshot|oneshot|auto: the arenas become peer-mapped regions of the
+        # direct xGMI all-reduce (collective call: same order on every rank)
+        c = _b.comm()
+        if c is not None and hasattr(c, "register_region"):
+            for dt in sorted(arena.grads, key=str):
+                c.register_region(arena.grads[dt])
+        self._ddl_metrics = _CommMetrics() if (c is not None and cfg.comm_metrics) else None
         if cfg.timeline and not _tl.enabled():
             _tl.start(cfg.timeline, _b.rank())
         if cfg.debug and _b.size() > 1:
@@ -133,7 +211,7 @@ class _DistributedMixin:
             raise RuntimeError("gradient bucket plans differ across ranks")
 
     # -- backward-time path ---------------------------------------------------------------
-    def _ddl_on_grad(self, p):
+    def _ddl_arrive(self, p):
         arena = self._ddl_arena
         arena.ensure_view(p)
         if not self._ddl_order_checked:
@@ -144,8 +222,18 @@ class _DistributedMixin:
             self._ddl_launch(st)
 
     def _ddl_on_direct_grad(self, p):
+        """Readiness of a gradient that a fused HIP block wrote straight into the arena.  autograd
+        runs the parameter's post-accumulate hook as well when the block's node returns - even
+        though the node hands back None for it (torch >= 2.x) - so the hook path skips parameters
+        served here; counting both launched every bucket after HALF of its gradients."""
         if id(p) in self._ddl_names:
-            self._ddl_on_grad(p)
+            self._ddl_direct_seen.add(id(p))
+            self._ddl_arrive(p)
+
+    def _ddl_on_grad(self, p):
+        if id(p) in self._ddl_direct_seen:
+            return
+        self._ddl_arrive(p)
 
     def _ddl_launch(self, st):
         st.launched = True
@@ -170,9 +258,13 @@ class _DistributedMixin:
         if st.work is None:
             return
         deadline = _b.engine_config().collective_timeout_s
+        m = self._ddl_metrics
+        e0 = m.before_wait() if (m is not None and st.tensor.is_cuda) else None
         # device collectives are stream-ordered (the host does not block); host ones wait here
         if not st.work.wait(deadline):
             raise RuntimeError("gradient allreduce timed out after %.0f s" % deadline)
+        if e0 is not None:
+            m.after_wait(e0)
         wire = st.wire
         if st.needs_scale:
             wire.div_(_b.size())
@@ -182,9 +274,7 @@ class _DistributedMixin:
         st.work = st.wire = st.ctx = None
         _tl.end("grad.%s.bucket%d" % (str(st.dtype).replace("torch.", ""), st.bucket.index))
 
-    def synchronize(self):
-        """Launch any bucket whose gradients did not all arrive (unused parameters) and order
-        the compute stream after every outstanding exchange."""
+    def _ddl_prepare_sync(self):
         if self._ddl_fault is not None:
             frank, fstep = self._ddl_fault
             if _b.rank() == frank and self._ddl_step_count == fstep:
@@ -198,9 +288,30 @@ class _DistributedMixin:
             _hip_ops._join_side_stream()
         except Exception:  # pragma: no cover - ops layer unavailable
             pass
+
+    def synchronize(self):
+        """Launch any bucket whose gradients did not all arrive (unused parameters) and order
+        the compute stream after every outstanding exchange."""
+        self._ddl_prepare_sync()
         for st in self._ddl_buckets:
             self._ddl_finish(st)
+        if self._ddl_metrics is not None:
+            self._ddl_metrics.end_step()
         self._ddl_verify_order_once()
+
+    def comm_metrics(self):
+        """{"comm_exposed_ms": last measured step, "comm_exposed_ms_mean", "bucket_ms": {name:
+        device ms of that bucket's last collective}} — None entries until measured."""
+        out = {"comm_exposed_ms": None, "comm_exposed_ms_mean": None, "bucket_ms": {}}
+        m = self._ddl_metrics
+        if m is not None and m.steps:
+            out["comm_exposed_ms"] = round(m.last_exposed_ms, 4)
+            out["comm_exposed_ms_mean"] = round(m.total_exposed_ms / m.steps, 4)
+        c = _b.comm()
+        if c is not None and hasattr(c, "stats"):
+            out["bucket_ms"] = {k: round(v["last_ms"], 4) for k, v in c.stats().items()
+                                if k.startswith("grad.")}
+        return out
 
     def _ddl_verify_order_once(self):
         if self._ddl_order_checked:
@@ -219,16 +330,33 @@ class _DistributedMixin:
         self._ddl_order_seen = []
 
     def _ddl_reset_buckets(self):
+        self._ddl_direct_seen.clear()
         for st in self._ddl_buckets:
             st.pending = st.expected
             st.launched = False
 
     # -- optimizer surface ----------------------------------------------------------------
     def step(self, closure=None):
-        self.synchronize()
+        base = super(self.__class__, self)
+        per_bucket = getattr(base, "step_bucket", None)
+        if per_bucket is None or closure is not None or not _b.engine_config().per_bucket_update:
+            self.synchronize()
+            self._ddl_reset_buckets()
+            self._ddl_step_count += 1
+            return base.step(closure)
+        # fused optimizer: wait for bucket k, update bucket k, wait for bucket k+1 ... - the
+        # update of the early buckets runs while the tail of the exchange is still in flight
+        self._ddl_prepare_sync()
+        base.begin_step()
+        for st in self._ddl_buckets:
+            self._ddl_finish(st)
+            per_bucket(st.dtype, st.bucket.start, st.bucket.end)
+        if self._ddl_metrics is not None:
+            self._ddl_metrics.end_step()
+        self._ddl_verify_order_once()
         self._ddl_reset_buckets()
         self._ddl_step_count += 1
-        return super(self.__class__, self).step(closure)
+        return base.end_step()
 
     def zero_grad(self, set_to_none=False):
         """Zero the arenas (one memset per dtype).  Gradients stay views into the arena, so

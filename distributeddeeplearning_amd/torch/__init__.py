@@ -7,8 +7,8 @@ surface named there (``shutdown``, ``local_size``, in-place/async variants, ``al
 ``BroadcastGlobalVariablesHook``) are exposed in PyTorch-side form.
 """
 from ..parallel.backend import (init, shutdown, is_initialized, rank, size, local_rank,
-                                local_size, cross_rank, cross_size, barrier,
-                                NotInitializedError)
+                                local_size, cross_rank, cross_size, barrier, comm, engine_name,
+                                backend_name, NotInitializedError)
 from ..parallel.collectives import (allreduce, allreduce_, allreduce_async, allreduce_async_,
                                     allgather, allgather_async, broadcast, broadcast_,
                                     broadcast_async, broadcast_async_, synchronize, poll,
@@ -47,5 +47,5 @@ __all__ = [
     "allgather_object", "broadcast_parameters", "broadcast_optimizer_state", "metric_average",
     "DistributedOptimizer", "Compression", "callbacks", "BroadcastGlobalVariablesHook",
     "Sum", "Average", "Min", "Max", "mpi_threads_supported", "nccl_built", "gloo_built",
-    "NotInitializedError",
+    "NotInitializedError", "comm", "engine_name", "backend_name",
 ]

@@ -168,18 +168,31 @@ class EngineConfig:
     # the last bucket (first layers, ready only when backward ends) holds at most this much, so the
     # bucket before it is exchanged while the stem's backward still runs
     tail_bucket_bytes: int = 256 * 1024
-    comm_dtype: str = "auto"  # auto = gradient dtype | bf16 | fp32
+    # dtype of the gradient arenas = dtype on the wire and of multi-pass accumulation:
+    # auto / bf16 = the parameter's dtype (bf16 conv/fc gradients, 51 MB per ResNet-50 step),
+    # fp32 = fp32 arenas for every parameter (102 MB; the split-K reduce writes fp32 directly)
+    comm_dtype: str = "auto"
     backend: str = "auto"  # auto | rccl | gloo
-    engine: str = "torch"  # torch (c10d process group) | native (in-tree C++ engine)
+    # auto = native on GPUs (in-tree C++ engine: RCCL called directly from its comm thread),
+    # torch.distributed's gloo on CPU | torch (c10d process group) | native
+    engine: str = "auto"
+    # rccl | twoshot | oneshot | auto: which all-reduce serves the gradient buckets (native engine
+    # on GPUs; twoshot/oneshot = the direct xGMI peer-access kernel, auto = by bucket size)
+    allreduce_algo: str = "rccl"
+    num_buckets: int = 0  # > 0: split every arena into this many equal buckets instead of the byte caps
     timeline: Optional[str] = None
     debug: bool = False
     collective_timeout_s: float = 300.0
     stall_warning_s: float = 60.0  # Horovod's stall-check default [EXT]
     fault_inject: Optional[str] = None  # "rank:step"
-    cycle_time_ms: float = 0.0  # accepted for Horovod compat; static buckets need no cycle
+    # Horovod's negotiation cycle.  Static buckets need none: a non-zero value is accepted for
+    # command-line compatibility and reported once at init as having no effect.
+    cycle_time_ms: float = 0.0
     # run the gradient exchange even with one rank (rehearses the RCCL path on a one-GPU box)
     force_collectives: bool = False
     high_priority_comm: bool = True   # RCCL collectives on a high-priority HIP stream (own hardware queue)
+    comm_metrics: bool = True         # per-step exposed-communication time from HIP events (never synchronises)
+    per_bucket_update: bool = True    # FusedSGD: update bucket k as soon as the stream has waited for bucket k
 
     @classmethod
     def from_env(cls) -> "EngineConfig":
@@ -190,7 +203,9 @@ class EngineConfig:
             tail_bucket_bytes=env_int("HVD_TAIL_BUCKET_BYTES", 256 * 1024),
             comm_dtype=env_str("HVD_COMM_DTYPE", "auto"),
             backend=env_str("HVD_BACKEND", "auto"),
-            engine=env_str("HVD_ENGINE", "torch"),
+            engine=env_str("HVD_ENGINE", "auto"),
+            allreduce_algo=env_str("HVD_ALLREDUCE_ALGO", "rccl"),
+            num_buckets=env_int("HVD_NUM_BUCKETS", 0),
             timeline=env_str("HVD_TIMELINE", None, "HOROVOD_TIMELINE"),
             debug=env_bool("HVD_DEBUG", False),
             collective_timeout_s=env_float("HVD_COLLECTIVE_TIMEOUT_S", 300.0),
@@ -200,4 +215,6 @@ class EngineConfig:
             cycle_time_ms=env_float("HVD_CYCLE_TIME", 0.0, "HOROVOD_CYCLE_TIME"),
             force_collectives=env_bool("HVD_FORCE_COLLECTIVES", False),
             high_priority_comm=env_bool("HVD_HIGH_PRIORITY_COMM", True),
+            comm_metrics=env_bool("HVD_COMM_METRICS", True),
+            per_bucket_update=env_bool("HVD_PER_BUCKET_UPDATE", True),
         )

@@ -39,6 +39,29 @@ def scenario_collectives():
     hvd.shutdown()
 
 
+def scenario_fp16():
+    """Compression.fp16 (and a raw fp16 / uint8 tensor) through the host data plane: the native
+    engine must REDUCE half precision (round 1 silently returned one rank's data)."""
+    hvd.init()
+    r, n = hvd.rank(), hvd.size()
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(n, 1000, generator=g) * 3
+    mine = base[r].clone()
+    avg = hvd.allreduce(mine, name="c.avg", compression=hvd.Compression.fp16)
+    half = base[r].to(torch.float16)
+    s16 = hvd.allreduce(half, average=False, name="h.sum")
+    mx16 = hvd.allreduce(half, op=hvd.Max, name="h.max")
+    tiny = torch.tensor([6e-8, 3e-5, 65504.0, -1e-7], dtype=torch.float16) * (1.0 if r == 0 else 0.0)
+    tsum = hvd.allreduce(tiny, average=False, name="h.edge")
+    u8 = hvd.allreduce(torch.full((4,), 10 * (r + 1), dtype=torch.uint8), average=False, name="u8")
+    exp_sum = base.to(torch.float16).float().sum(0)
+    exp_avg = base.to(torch.float16).float().mean(0)
+    emit(rank=r, avg_err=float((avg - exp_avg).abs().max()), sum_err=float((s16.float() - exp_sum).abs().max()),
+         max_ok=bool(torch.equal(mx16, base.to(torch.float16).max(0).values)),
+         edge=tsum.float().tolist(), u8=u8.tolist(), dtype=str(s16.dtype))
+    hvd.shutdown()
+
+
 def _tiny_model():
     torch.manual_seed(1234)
     return torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.BatchNorm2d(4),

@@ -188,3 +188,44 @@ def test_tail_bucket_keeps_the_last_exchange_small():
     for b in tail.buckets:
         assert all(b.start <= s.offset and s.offset + s.numel <= b.end for s in b.segments)
     assert all(a.end == b.start for a, b in zip(tail.buckets, tail.buckets[1:]))
+
+
+def test_direct_gradients_are_counted_once_per_backward():
+    """A fused block writes a gradient into the arena itself, reports it through the ops layer's
+    listener and returns None to autograd - and autograd STILL runs the parameter's
+    post-accumulate hook (torch >= 2.x).  Counting both launched every bucket after half of its
+    gradients had arrived (found on the GPU by test_bucket_is_complete_when_its_collective_runs)."""
+    import distributeddeeplearning_amd.torch as hvd
+    from distributeddeeplearning_amd.ops import hip_ops
+
+    hvd.init()
+    w1 = torch.nn.Parameter(torch.ones(4))
+    w2 = torch.nn.Parameter(torch.ones(4))
+
+    class Direct(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.w = w
+            return x * w.detach()
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.w.grad.add_(g)          # "kernel" writes the arena view
+            hip_ops._notify(ctx.w)      # ... and reports readiness
+            return g * ctx.w.detach(), None
+
+    opt = hvd.DistributedOptimizer(torch.optim.SGD([w1, w2], lr=0.1), named_parameters=[("w1", w1), ("w2", w2)])
+    assert len(opt._ddl_buckets) == 1
+    seen = {}
+    x = torch.ones(4, requires_grad=True)
+    h = Direct.apply(x, w1)
+    def between(g):
+        seen["launched_after_w2_only"] = opt._ddl_buckets[0].launched
+
+    h.register_hook(between)
+    opt.zero_grad()
+    Direct.apply(h, w2).sum().backward()
+    assert seen["launched_after_w2_only"] is False
+    assert opt._ddl_buckets[0].launched and opt._ddl_buckets[0].pending == 0
+    opt.step()
+    assert torch.allclose(w1.detach(), torch.full((4,), 0.9)) and torch.allclose(w2.detach(), torch.full((4,), 0.9))

@@ -56,6 +56,19 @@ def test_collectives_np2(engine):
     assert "[0]<localhost>" in out and "[1]<localhost>" in out  # per-rank output tagging
 
 
+@pytest.mark.parametrize("engine", ["torch", "native"])
+def test_half_precision_and_uint8_are_reduced(engine):
+    rc, res, out = _launch("fp16", exports={"HVD_ENGINE": engine})
+    assert rc == 0, out
+    for r in (0, 1):
+        rec = res[r]
+        assert rec["dtype"] == "torch.float16"
+        assert rec["sum_err"] < 0.02 and rec["avg_err"] < 0.01, rec   # one fp16 rounding of a |x| < 20 sum
+        assert rec["max_ok"] and rec["u8"] == [30] * 4
+        exp = torch.tensor([6e-8, 3e-5, 65504.0, -1e-7], dtype=torch.float16).float().tolist()
+        assert rec["edge"] == exp   # subnormal / max-normal halves survive the fp32 round trip
+
+
 @pytest.mark.parametrize("fused,engine", [("0", "torch"), ("1", "torch"), ("1", "native")])
 def test_distributed_optimizer_equals_large_batch(fused, engine):
     rc, res, out = _launch("optimizer_equivalence", exports={"TEST_FUSED": fused,

@@ -1,0 +1,176 @@
+"""The native engine as the GPU data plane: RCCL called by the engine's comm
+thread on its own stream, the direct xGMI all-reduce over REAL hipIpc mappings between REAL
+processes sharing the one GPU of the test box, the device-collective watchdog, and data-parallel
+equivalence on the HIP bf16 path."""
+import io
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from distributeddeeplearning_amd.launch import run as ddlrun
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+WORKER = os.path.join(HERE, "gpu_worker.py")
+
+
+def _launch(scenario, np_total=2, exports=None, timeout=240):
+    sink = io.StringIO()
+    # DDL_COMM_STREAM_PRIORITY=low: the ranks share ONE GPU here, and a resident high-priority kernel
+    # that spins on a peer's flag starves that peer process's compute queues (measured: the peer's
+    # backward pass did not advance for 16 s, profiles/r2_notes.md); on one GPU per rank the comm
+    # stream keeps its high priority
+    env = {"OMP_NUM_THREADS": "2", "DDL_RCCL_SKIP_COMM": "1", "HVD_ALLREDUCE_ALGO": "twoshot",
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0", "HVD_COLLECTIVE_TIMEOUT_S": "60",
+           "DDL_COMM_STREAM_PRIORITY": "low"}
+    env.update(exports or {})
+    # every rank on GPU 0: one slot per rank but LOCAL_RANK is irrelevant with one visible device
+    rc = ddlrun.launch([sys.executable, "-u", WORKER, scenario], np_total,
+                       hosts=[("localhost", np_total)], exports=env, timeout=timeout, sink=sink)
+    out = sink.getvalue()
+    try:  # full per-rank output for post-mortems (gpurun merges gpurun_out/ back)
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "engine_tests"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "engine_tests", "%s_np%d.log" % (scenario, np_total)), "w") as fh:
+            fh.write(out)
+    except OSError:
+        pass
+    results = {}
+    for line in out.splitlines():
+        if "RESULT " in line:
+            rec = json.loads(line.split("RESULT ", 1)[1])
+            results[rec["rank"]] = rec
+            print(line[:600])   # shown by pytest -s / on failure
+    return rc, results, out
+
+
+def test_forced_collectives_run_through_native_rccl():
+    """One rank, HVD_FORCE_COLLECTIVES=1: hvd.* device collectives go engine comm thread ->
+    ncclCommInitRank / ncclAllReduce / ncclBroadcast / ncclAllGather on the engine's stream."""
+    code = r'''
+import os, json, torch
+os.environ["HVD_FORCE_COLLECTIVES"] = "1"
+os.environ["MASTER_PORT"] = str(29500 + os.getpid() % 2000)
+import distributeddeeplearning_amd.torch as hvd
+hvd.init()
+assert hvd.engine_name() == "native" and hvd.backend_name() == "rccl", (hvd.engine_name(), hvd.backend_name())
+c = hvd.comm()
+x = torch.randn(1 << 20, device="cuda").to(torch.bfloat16)
+y = x * 2
+ref = y.clone()
+h = hvd.allreduce_async_(y, average=True, name="g")
+hvd.synchronize(h)
+z = y + 0
+b = torch.arange(16., device="cuda"); hvd.broadcast_(b, 0, name="b")
+g = hvd.allgather(torch.ones(3, 2, device="cuda"), name="ag")
+m = hvd.allreduce(torch.tensor([1.5], dtype=torch.float64, device="cuda"), op=hvd.Max, name="mx")
+torch.cuda.synchronize()
+import time; time.sleep(0.5)
+counts = c.launch_counts(); stats = c.stats()
+print("RESULT " + json.dumps({"equal": bool(torch.equal(z, ref)), "rccl": counts["rccl"], "g": g.shape[0],
+      "mx": float(m), "stats": sorted(stats), "g_ms": stats.get("g", {}).get("last_ms", -1),
+      "stream": int(c.lib.ddl_rccl_stream() or 0) != int(torch.cuda.current_stream().cuda_stream)}))
+hvd.shutdown()
+'''
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads(out.stdout.split("RESULT ", 1)[1].splitlines()[0])
+    assert rec["equal"] and rec["rccl"] >= 4 and rec["g"] == 3 and rec["mx"] == 1.5
+    assert "g" in rec["stats"] and rec["g_ms"] >= 0 and rec["stream"]
+
+
+def test_bucket_is_complete_when_its_collective_runs():
+    """Gating of the gradient exchange: right before every bucket's all-reduce the same gate (event
+    on the producer stream -> engine stream) feeds an all-gather of the bucket into a snapshot.
+    With one rank the all-reduce is the identity, so every snapshot must equal the final arena: a
+    bucket whose collective could start before its last weight gradient landed (side stream!)
+    shows up as a difference."""
+    code = r'''
+import os, json, torch
+os.environ["HVD_FORCE_COLLECTIVES"] = "1"
+os.environ["MASTER_PORT"] = str(31500 + os.getpid() % 2000)
+import distributeddeeplearning_amd.torch as hvd
+from distributeddeeplearning_amd.models import resnet18, resnet50
+from distributeddeeplearning_amd.ops import functional as ops
+from distributeddeeplearning_amd.optim import FusedSGD
+hvd.init()
+c = hvd.comm()
+dev = torch.device("cuda", 0)
+out = {}
+for name, ctor, batch, res in (("resnet18", resnet18, 4, 64), ("resnet50", resnet50, 8, 96)):
+    torch.manual_seed(3)
+    m = ctor(num_classes=64).to_compute(dev, torch.bfloat16).train()
+    opt = hvd.DistributedOptimizer(FusedSGD(m.named_parameters(), lr=0.01, momentum=0.9),
+                                   named_parameters=m.named_parameters())
+    snaps = {}
+    real = c.all_reduce
+    def spy(tensor, op, name=None, _real=real):
+        snap = torch.empty((1,) + tuple(tensor.shape), dtype=tensor.dtype, device=tensor.device)
+        c.all_gather_into(snap, tensor, name="snap." + str(name)).wait()
+        snaps[name] = (snap, tensor)
+        return _real(tensor, op, name)
+    c.all_reduce = spy
+    x = torch.rand(batch, 3, res, res, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, 64, (batch,), device=dev)
+    bad = {}
+    for it in range(3):
+        opt.zero_grad()
+        ops.softmax_cross_entropy(m(x), y).backward()
+        opt.synchronize()
+        torch.cuda.synchronize()
+        for k, (snap, t) in snaps.items():
+            d = int((snap[0] != t).sum())
+            if d:
+                bad["%s.it%d" % (k, it)] = d
+        opt._ddl_reset_buckets()
+    c.all_reduce = real
+    out[name] = {"buckets": len(snaps), "bad": bad}
+    del opt, m
+print("RESULT " + json.dumps(out))
+hvd.shutdown()
+'''
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads(out.stdout.split("RESULT ", 1)[1].splitlines()[0])
+    print(rec)
+    for name in ("resnet18", "resnet50"):
+        assert rec[name]["buckets"] >= 3 and rec[name]["bad"] == {}, rec
+
+
+def test_xgmi_allreduce_two_processes_one_gpu_every_word():
+    rc, res, out = _launch("xgmi_words")
+    assert rc == 0, out[-4000:]
+    assert set(res) == {0, 1}, out[-4000:]
+    for r in (0, 1):
+        assert res[r]["bad"] == [], res[r]["bad"][:5]
+        assert res[r]["xgmi"] == res[r]["launches"] and res[r]["rccl"] == 0
+        assert not res[r]["failed"] and res[r]["stats"] > 0
+
+
+def test_xgmi_allreduce_four_processes_one_gpu():
+    rc, res, out = _launch("xgmi_words", np_total=4)
+    assert rc == 0, out[-4000:]
+    assert set(res) == {0, 1, 2, 3}
+    assert all(res[r]["bad"] == [] for r in res)
+
+
+def test_xgmi_missing_peer_becomes_python_error():
+    rc, res, out = _launch("xgmi_timeout", exports={"HVD_XGMI_SPIN_LIMIT": "20000"}, timeout=120)
+    assert 0 in res and 1 in res, out[-4000:]
+    assert res[0]["raised"] and res[0]["failed"], res[0]
+    assert "spin limit" in res[0]["kind"] or "collective" in res[0]["kind"]
+    assert res[0]["seconds"] < 30
+
+
+def test_data_parallel_equivalence_hip_bf16_through_xgmi():
+    rc, res, out = _launch("dp_equivalence", timeout=300)
+    assert rc == 0, out[-4000:]
+    for r in (0, 1):
+        assert all(v == 0 for v in res[r]["mismatches"].values()), res[r]["mismatches"]
+        assert res[r]["xgmi"] > 0
+    assert res[0]["checksum"] == res[1]["checksum"] and res[0]["absmax"] == res[1]["absmax"]

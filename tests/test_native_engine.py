@@ -75,12 +75,20 @@ def test_engine_single_rank_store_and_handles(tmp_path):
 
 
 @pytest.mark.gpu
-def test_rccl_backend_single_gpu_event_plumbing():
-    """The direct RCCL data plane on one MI355X (communicator of size 1): stream-ordered
-    all-reduce / broadcast through event hand-offs, no host synchronisation."""
-    for fn in ("ddl_rccl_allreduce", "ddl_rccl_broadcast"):
-        getattr(lib, fn).restype = ctypes.c_longlong
+def test_engine_device_plane_single_gpu_event_plumbing():
+    """The engine's device plane on one MI355X (communicator of size 1): the comm thread issues
+    ncclAllReduce / ncclBroadcast on the plane's own stream; ordering with the torch stream is by
+    events only (no host synchronisation), handles poll and wait like host handles."""
+    lib.ddl_eng_device_collective.restype = ctypes.c_longlong
+    lib.ddl_eng_device_collective.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_char_p]
+    lib.ddl_eng_device_wait.argtypes = [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_double]
+    lib.ddl_eng_device_wait_host.argtypes = [ctypes.c_longlong, ctypes.c_double]
     lib.ddl_rccl_last_error.restype = ctypes.c_char_p
+    lib.ddl_eng_last_error.restype = ctypes.c_char_p
+    lib.ddl_rccl_stream.restype = ctypes.c_void_p
+    lib.ddl_rccl_launch_count.restype = ctypes.c_longlong
     port = _free_port()
     assert lib.ddl_eng_init(0, 1, b"127.0.0.1", port, ctypes.c_double(30.0), ctypes.c_double(10.0)) == 0
     try:
@@ -88,16 +96,18 @@ def test_rccl_backend_single_gpu_event_plumbing():
         x = torch.randn(1 << 20, device="cuda").to(torch.bfloat16)
         ref = (x.float() * 2).to(torch.bfloat16)
         y = x * 2  # producer kernel on the torch stream; the collective must wait for it
-        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        h = lib.ddl_rccl_allreduce(ctypes.c_void_p(y.data_ptr()), ctypes.c_longlong(y.numel()), 3, 1, s, b"g")
-        assert h > 0, lib.ddl_rccl_last_error()
-        assert lib.ddl_rccl_wait_stream(ctypes.c_longlong(h), s) == 0
+        s = torch.cuda.current_stream().cuda_stream
+        assert lib.ddl_rccl_stream() not in (None, s)
+        h = lib.ddl_eng_device_collective(0, y.data_ptr(), None, y.numel(), 3, 1, 0, 0, s, b"g")
+        assert h > 0, lib.ddl_eng_last_error()
+        assert lib.ddl_eng_device_wait(h, s, 10.0) == 0, lib.ddl_eng_last_error()
         z = y + 0  # consumer ordered after the collective
         torch.cuda.synchronize()
         assert torch.equal(z, ref)
-        h = lib.ddl_rccl_broadcast(ctypes.c_void_p(y.data_ptr()), ctypes.c_longlong(y.numel()), 3, 0, s, b"b")
-        assert lib.ddl_rccl_wait_host(ctypes.c_longlong(h)) == 0
-        assert lib.ddl_rccl_poll(ctypes.c_longlong(h)) == -1
+        h = lib.ddl_eng_device_collective(1, y.data_ptr(), None, y.numel(), 3, 0, 0, 0, s, b"b")
+        assert lib.ddl_eng_device_wait_host(h, 10.0) == 0
+        assert lib.ddl_eng_poll(ctypes.c_longlong(h)) == -1  # consumed
+        assert lib.ddl_rccl_launch_count() == 2 and lib.ddl_eng_failed() == 0
     finally:
         lib.ddl_rccl_shutdown()
         lib.ddl_eng_shutdown()
