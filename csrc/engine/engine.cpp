@@ -323,6 +323,7 @@ public:
     }
 
     bool failed() const { return device_failed_.load(); }
+    void harvest() { watch_device(); }
 
     // "name count last_ms mean_ms algo bytes" per line: device time of every named collective
     std::string stats_text() {
@@ -761,6 +762,7 @@ int ddl_eng_failed() { return g_engine && g_engine->failed() ? 1 : 0; }
 // per-collective device times ("name count last_ms mean_ms algo bytes" lines); returns the length
 long long ddl_eng_stats(char* buf, long long cap) {
     if (!g_engine || !buf || cap <= 0) return -1;
+    g_engine->harvest();   // record collectives that completed since the watchdog's last pass
     const std::string t = g_engine->stats_text();
     const long long n = (long long)t.size() < cap - 1 ? (long long)t.size() : cap - 1;
     std::memcpy(buf, t.data(), (size_t)n);

@@ -49,7 +49,8 @@ def scenario_xgmi_words():
         comm.register_region(arena[dt])
     launches = 0
     stamp("regions registered")
-    for epoch in range(3):
+    for epoch in range(int(os.environ.get("TEST_EPOCHS", "3"))):
+        stamp("epoch %d" % epoch)
         for dt in (torch.bfloat16, torch.float32):
             for numel, off in ((16 * n, 0), (4096 * n, 1024), (1 << 20, 65536), ((3 << 20) - 16 * n * 8, 16 * n * 8)):
                 numel = numel // (8 * n) * (8 * n)
@@ -69,8 +70,7 @@ def scenario_xgmi_words():
                     if op == "average":
                         exp = exp * (1.0 / n)
                     exp = exp.to(dt)
-                    if launches < 2:
-                        stamp("launching collective %d" % launches)
+                    stamp("collective %d %s %s %d" % (launches, algo, str(dt)[6:], numel))
                     h = hvd.allreduce_async_(buf, op=hvd.Average if op == "average" else hvd.Sum,
                                              name="w.%s.%s.%d.%d" % (algo, str(dt)[6:], numel, epoch))
                     hvd.synchronize(h)

@@ -20,26 +20,39 @@ ROOT = os.path.dirname(HERE)
 WORKER = os.path.join(HERE, "gpu_worker.py")
 
 
+class _Tee(io.StringIO):
+    """Launcher sink that also appends to a file as lines arrive: a run that is killed from outside
+    still leaves its per-rank output under gpurun_out/ (gpurun merges that directory back)."""
+
+    def __init__(self, path):
+        super().__init__()
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            self.fh = open(path, "w")
+        except OSError:
+            self.fh = None
+
+    def write(self, text):
+        if self.fh is not None:
+            self.fh.write(text)
+            self.fh.flush()
+        return super().write(text)
+
+
 def _launch(scenario, np_total=2, exports=None, timeout=240):
-    sink = io.StringIO()
+    sink = _Tee(os.path.join(ROOT, "gpurun_out", "engine_tests", "%s_np%d.log" % (scenario, np_total)))
     # DDL_COMM_STREAM_PRIORITY=low: the ranks share ONE GPU here, and a resident high-priority kernel
     # that spins on a peer's flag starves that peer process's compute queues (measured: the peer's
     # backward pass did not advance for 16 s, profiles/r2_notes.md); on one GPU per rank the comm
     # stream keeps its high priority
     env = {"OMP_NUM_THREADS": "2", "DDL_RCCL_SKIP_COMM": "1", "HVD_ALLREDUCE_ALGO": "twoshot",
            "HSA_ENABLE_IPC_MODE_LEGACY": "0", "HVD_COLLECTIVE_TIMEOUT_S": "60",
-           "DDL_COMM_STREAM_PRIORITY": "low"}
+           "DDL_COMM_STREAM_PRIORITY": "low", "TEST_STAMPS": "1"}
     env.update(exports or {})
     # every rank on GPU 0: one slot per rank but LOCAL_RANK is irrelevant with one visible device
     rc = ddlrun.launch([sys.executable, "-u", WORKER, scenario], np_total,
                        hosts=[("localhost", np_total)], exports=env, timeout=timeout, sink=sink)
     out = sink.getvalue()
-    try:  # full per-rank output for post-mortems (gpurun merges gpurun_out/ back)
-        os.makedirs(os.path.join(ROOT, "gpurun_out", "engine_tests"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "engine_tests", "%s_np%d.log" % (scenario, np_total)), "w") as fh:
-            fh.write(out)
-    except OSError:
-        pass
     results = {}
     for line in out.splitlines():
         if "RESULT " in line:
@@ -153,7 +166,7 @@ def test_xgmi_allreduce_two_processes_one_gpu_every_word():
 
 
 def test_xgmi_allreduce_four_processes_one_gpu():
-    rc, res, out = _launch("xgmi_words", np_total=4)
+    rc, res, out = _launch("xgmi_words", np_total=4, exports={"TEST_EPOCHS": "1"}, timeout=150)
     assert rc == 0, out[-4000:]
     assert set(res) == {0, 1, 2, 3}
     assert all(res[r]["bad"] == [] for r in res)
