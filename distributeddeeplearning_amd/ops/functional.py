@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 
 __all__ = ["use_hip", "conv2d", "conv_bn_act", "residual_block", "batchnorm_act", "maxpool3x3s2", "global_avgpool", "linear",
-           "softmax_cross_entropy", "topk_correct", "set_backend", "backend"]
+           "softmax_cross_entropy", "topk_correct", "topk_hits", "NoHipKernel", "set_backend", "backend"]
 
 _FORCED = os.environ.get("DDL_OPS", "auto").lower()  # auto | hip | aten
 
@@ -41,17 +41,28 @@ def backend() -> str:
     return _FORCED
 
 
+class NoHipKernel(RuntimeError):
+    """A GPU tensor reached an op the HIP kernels do not serve.  There is ONE code path on the GPU:
+    nothing falls back to ATen/MIOpen unless ``DDL_OPS=aten`` asks for the oracle explicitly."""
+
+
 def use_hip(t: torch.Tensor) -> bool:
-    """HIP kernels serve CUDA(HIP)-device bf16 tensors unless DDL_OPS=aten."""
+    """HIP kernels serve every GPU tensor (bf16 activations) unless ``DDL_OPS=aten`` selects the
+    PyTorch oracle; CPU tensors always take the PyTorch path."""
     if _FORCED == "aten" or not t.is_cuda:
         return False
     if t.dtype != torch.bfloat16:
-        if _FORCED == "hip":
-            raise RuntimeError("DDL_OPS=hip requires bf16 activations, got %s" % t.dtype)
-        return False
+        raise NoHipKernel("the HIP kernels compute in bf16, got a %s tensor on %s: move the model with "
+                          ".to_compute(device, torch.bfloat16) and feed bf16 batches, or set DDL_OPS=aten "
+                          "for the PyTorch oracle" % (t.dtype, t.device))
     from . import kernels
 
     return kernels.require()
+
+
+def _no_kernel(op, what):
+    raise NoHipKernel("ops.%s: no HIP kernel for %s (set DDL_OPS=aten to run the PyTorch oracle instead)"
+                      % (op, what))
 
 
 # ------------------------------------------------------------------------------------------
@@ -61,22 +72,9 @@ def conv2d(x, weight, stride=1, padding=0):
 
         if hip_ops.conv_supported(weight, stride, padding):
             return hip_ops.conv2d(x, weight, stride, padding)
-        _warn_once("conv2d", "Cin=%d Cout=%d %dx%d" % (weight.shape[1], weight.shape[0],
-                                                        weight.shape[2], weight.shape[3]))
+        _no_kernel("conv2d", "Cin=%d Cout=%d %dx%d stride %s" % (weight.shape[1], weight.shape[0],
+                                                                  weight.shape[2], weight.shape[3], stride))
     return F.conv2d(x, weight.to(x.dtype), None, stride, padding)
-
-
-_warned = set()
-
-
-def _warn_once(op, what):
-    """Shapes outside the HIP kernels' envelope run on ATen — loudly, never silently."""
-    key = (op, what)
-    if key not in _warned:
-        _warned.add(key)
-        import warnings
-
-        warnings.warn("ops.%s: no HIP kernel for %s; using the ATen implementation" % (op, what))
 
 
 def conv_bn_act(x, weight, stride, padding, gamma, beta, running_mean, running_var, training,
@@ -91,6 +89,7 @@ def conv_bn_act(x, weight, stride, padding, gamma, beta, running_mean, running_v
             y, stats = hip_ops.conv2d_stats(x, weight, stride, padding, bool(training))
             return hip_ops.batchnorm_act(y, gamma, beta, running_mean, running_var, training,
                                          momentum, eps, relu, residual, stats)
+        _no_kernel("conv_bn_act", "weight %s stride %s" % (tuple(weight.shape), stride))
     y = conv2d(x, weight, stride, padding)
     return batchnorm_act(y, gamma, beta, running_mean, running_var, training, momentum, eps, relu,
                          residual)
@@ -109,6 +108,7 @@ def residual_block(x, units, downsample, training, momentum=0.1, eps=1e-5):
         convs = [u[0] for u in units] + ([downsample[0]] if downsample is not None else [])
         if hip_ops.residual_block_supported(convs):
             return hip_ops.residual_block(x, units, downsample, training, momentum, eps)
+        _no_kernel("residual_block", "convolutions %s" % [tuple(w.shape) for w in convs])
     shortcut = x
     if downsample is not None:
         w, s, g, b, rm, rv = downsample
@@ -148,6 +148,7 @@ def residual_chain(x, blocks, training, momentum=0.1, eps=1e-5):
                 [u[0] for u in units] + ([ds[0]] if ds is not None else []))
                for units, ds in blocks):
             return hip_ops.residual_chain(x, blocks, training, momentum, eps)
+        _no_kernel("residual_chain", "one of the blocks' convolutions")
     for units, ds in blocks:
         x = residual_block(x, units, ds, training, momentum, eps)
     return x
@@ -163,7 +164,7 @@ def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum=
         if hip_ops.bn_supported(x.shape[1]):
             return hip_ops.batchnorm_act(x, gamma, beta, running_mean, running_var, training,
                                          momentum, eps, relu, residual)
-        _warn_once("batchnorm_act", "C=%d" % x.shape[1])
+        _no_kernel("batchnorm_act", "C=%d" % x.shape[1])
     y = F.batch_norm(x.float() if x.dtype != torch.float32 and not x.is_cuda else x,
                      running_mean, running_var, gamma, beta, training, momentum, eps)
     y = y.to(x.dtype)
@@ -195,7 +196,7 @@ def linear(x, weight, bias=None):
 
         if x.dim() == 2 and hip_ops.linear_supported(weight):
             return hip_ops.linear(x, weight, bias)
-        _warn_once("linear", "in=%d out=%d" % (weight.shape[1], weight.shape[0]))
+        _no_kernel("linear", "in=%d out=%d on a %d-d input" % (weight.shape[1], weight.shape[0], x.dim()))
     return F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
 
 
@@ -211,16 +212,29 @@ def softmax_cross_entropy(logits, target):
     return F.cross_entropy(logits.float(), target)
 
 
-def topk_correct(logits, target, ks=(1, 5)):
-    """Number of samples whose label is within the top-k logits, for each k (eval metric;
-    ``imagenet_keras_horovod.py:307`` accuracy + top_k_categorical_accuracy)."""
-    if use_hip(logits) and logits.dim() == 2 and logits.dtype == torch.bfloat16 and \
-            logits.stride(1) == 1:
+def topk_hits(logits, target, ks=(1, 5)):
+    """Per-k count of samples whose label is within the top-k logits, as a float64 tensor on the
+    logits' device - no host synchronisation, so evaluation loops accumulate it and read once
+    (eval metric: ``imagenet_keras_horovod.py:307`` accuracy + top_k_categorical_accuracy,
+    ``imagenet_estimator_tf_horovod.py:209-213``).  On the GPU this is K21: one wave per row finds
+    the rank of the label's logit, no sort and no [B, k] index tensor."""
+    if logits.is_cuda and _FORCED != "aten":
         from . import kernels as K
 
-        rank = K.label_rank(logits, target.contiguous())  # one wave per row, no sort
-        return [int((rank < k).sum().item()) for k in ks]
+        K.require()
+        if logits.dim() != 2:
+            _no_kernel("topk_hits", "a %d-d logits tensor" % logits.dim())
+        lg = logits.detach()
+        if lg.dtype != torch.bfloat16 or lg.stride(1) != 1:
+            lg = lg.to(torch.bfloat16).contiguous()   # the classifier head emits bf16; fp32 callers are rounded once
+        rank = K.label_rank(lg, target.contiguous())
+        return torch.stack([(rank < k).sum() for k in ks]).double()
     maxk = max(ks)
-    _, pred = logits.float().topk(maxk, dim=1)
+    _, pred = logits.detach().float().topk(maxk, dim=1)
     hit = pred.eq(target.view(-1, 1))
-    return [int(hit[:, :k].any(dim=1).sum().item()) for k in ks]
+    return torch.stack([hit[:, :k].any(dim=1).sum() for k in ks]).double()
+
+
+def topk_correct(logits, target, ks=(1, 5)):
+    """:func:`topk_hits` as Python ints (one device synchronisation)."""
+    return [int(v) for v in topk_hits(logits, target, ks).tolist()]

@@ -105,16 +105,20 @@ class _ArenaOptimizer(Optimizer):
         ``sync_lr()`` — outside the graph — rewrites that float when ``param_groups[0]["lr"]``
         moved.  HIP kernels only; the CPU reference path keeps reading ``lr`` directly."""
         if self.lr_scale is None:
-            self._frozen_lr = float(self.param_groups[0]["lr"])
-            self.lr_scale = torch.ones(1, dtype=torch.float32, device=self.arena.device)
-            self._scale_written = 1.0
+            lr = float(self.param_groups[0]["lr"])
+            # a warm-up that starts at lr = 0 must not freeze a zero: the by-value factor is 1.0
+            # then and the device scalar carries the absolute learning rate
+            self._frozen_lr = lr if lr != 0.0 else 1.0
+            self._scale_written = lr / self._frozen_lr
+            self.lr_scale = torch.full((1,), self._scale_written, dtype=torch.float32,
+                                       device=self.arena.device)
         return self.lr_scale
 
     def sync_lr(self):
         if self.lr_scale is None:
             return
         lr = float(self.param_groups[0]["lr"])
-        scale = lr / self._frozen_lr if self._frozen_lr != 0.0 else 0.0
+        scale = lr / self._frozen_lr
         if scale != self._scale_written:
             self.lr_scale.fill_(scale)
             self._scale_written = scale

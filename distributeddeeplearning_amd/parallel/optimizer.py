@@ -31,6 +31,7 @@ import os
 
 import torch
 
+from ..utils import trace as _trace
 from . import backend as _b
 from . import timeline as _tl
 from .bucket import GradArena, arena_options
@@ -241,6 +242,7 @@ class _DistributedMixin:
             return
         name = "grad.%s.bucket%d" % (str(st.dtype).replace("torch.", ""), st.bucket.index)
         _tl.begin(name, "ALLREDUCE")
+        _trace.mark("launch " + name)
         buf = st.tensor
         with _grad_exchange_context():
             wire, ctx = self._ddl_compression.compress(buf)
@@ -349,8 +351,9 @@ class _DistributedMixin:
         self._ddl_prepare_sync()
         base.begin_step()
         for st in self._ddl_buckets:
-            self._ddl_finish(st)
-            per_bucket(st.dtype, st.bucket.start, st.bucket.end)
+            with _trace.range("wait+update %s.bucket%d" % (str(st.dtype).replace("torch.", ""), st.bucket.index)):
+                self._ddl_finish(st)
+                per_bucket(st.dtype, st.bucket.start, st.bucket.end)
         if self._ddl_metrics is not None:
             self._ddl_metrics.end_step()
         self._ddl_verify_order_once()

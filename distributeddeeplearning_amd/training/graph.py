@@ -21,7 +21,9 @@ What makes the framework's step capturable:
 * nothing in the step reads a value back to the host; the loss stays on the device;
 * the learning rate is a by-value kernel argument times a device-side scalar
   (``optim/fused.py::freeze_lr``), so LR schedules keep working: :meth:`GraphedTrainStep.__call__`
-  rewrites that scalar outside the graph when ``param_groups[0]["lr"]`` moved.
+  rewrites that scalar outside the graph when ``param_groups[0]["lr"]`` moved.  Momentum, weight
+  decay and the other hyper-parameters are by-value arguments: a step on which they differ from
+  the captured ones (momentum correction) runs eagerly;
 
 The first ``warmup`` calls run eagerly (lazy initialisation: kernel library, side stream,
 transposed-weight tables, MIOpen-free but allocator warm-up), the next call captures and
@@ -59,6 +61,13 @@ class GraphedTrainStep:
         self._static_in = None
         self._static_loss = None
         self._pool = None
+        self._captured_hyper = None
+
+    def _hyper(self):
+        """Everything but the learning rate is a by-value kernel argument inside the graph."""
+        return [tuple((k, v) for k, v in sorted(g.items()) if k not in ("params", "lr") and
+                      isinstance(v, (int, float, bool)))
+                for g in self.optimizer.param_groups]
 
     # ---------------------------------------------------------------------------------------
     def _eager(self, images, labels):
@@ -106,6 +115,7 @@ class GraphedTrainStep:
             return False
         _hip_ops.set_wgrad_side_stream(side_was_on)
         self.graph = g
+        self._captured_hyper = self._hyper()
         return True
 
     def __call__(self, images, labels):
@@ -123,6 +133,10 @@ class GraphedTrainStep:
             self.optimizer.sync_lr()   # the frozen learning rate lives in a device scalar from now on
         if images.shape != si.shape or labels.shape != sl.shape or images.dtype != si.dtype:
             # e.g. the short last batch of an epoch: the graph is for one shape only
+            return self._eager(images, labels)
+        if self._hyper() != self._captured_hyper:
+            # momentum / weight decay were captured by value: a callback that moves them (the
+            # one-step momentum correction of the LR schedule callbacks) gets an eager step
             return self._eager(images, labels)
         if images.data_ptr() != si.data_ptr():
             si.copy_(images, non_blocking=True)

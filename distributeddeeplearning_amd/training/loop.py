@@ -23,6 +23,7 @@ from .. import torch as hvd
 from ..data import DevicePrefetcher, DeviceSyntheticLoader, FakeData, get_sampler
 from ..data import imagenet as _imagenet
 from ..ops import functional as ops
+from ..utils import trace
 from ..utils.timer import Timer
 
 __all__ = ["train_epoch", "validate", "log_summary", "to_device_batch", "build_data",
@@ -84,11 +85,15 @@ def train_epoch(loader, model, criterion, optimizer, epoch, logger, device, dtyp
         if graph_step is not None:
             loss = graph_step(data, target)
         else:
+            # roctx ranges (DDL_ROCTX=1) for rocprofv3 --marker-trace timelines; no-ops otherwise
             optimizer.zero_grad()
-            output = model(data)
-            loss = criterion(output, target)
-            loss.backward()
-            optimizer.step()
+            with trace.range("fwd"):
+                output = model(data)
+                loss = criterion(output, target)
+            with trace.range("bwd"):
+                loss.backward()
+            with trace.range("step"):
+                optimizer.step()
         n = len(data)
         samples += n
         if steady_on:
@@ -99,8 +104,14 @@ def train_epoch(loader, model, criterion, optimizer, epoch, logger, device, dtyp
             last_loss = float(loss.detach())  # the only device sync of the interval
             logger.info(_TRAIN_MSG.format(t.elapsed, last_loss, i * n))
             if metrics is not None:
+                extra = {}
+                cm = getattr(optimizer, "comm_metrics", None)
+                if cm is not None:  # exposed communication time and per-bucket device ms
+                    m = cm()
+                    if m["comm_exposed_ms"] is not None or m["bucket_ms"]:
+                        extra = {"comm_exposed_ms": m["comm_exposed_ms"], "bucket_ms": m["bucket_ms"]}
                 metrics.write(kind="train", epoch=epoch, step=i, loss=last_loss,
-                              interval_s=t.elapsed)
+                              interval_s=t.elapsed, **extra)
             t.start()
             if i == 0:  # the device is idle here: start the warm-up-free clock
                 steady.start()
@@ -140,10 +151,7 @@ def validate(loader, model, criterion, logger, device, dtype, log_interval=100, 
         loss = criterion(output, target)
         n = len(data)
         tot_loss += loss.detach().double() * n
-        _, pred = output.float().topk(5, dim=1)
-        hit = pred.eq(target.view(-1, 1))
-        correct[0] += hit[:, :1].any(dim=1).sum()
-        correct[1] += hit.any(dim=1).sum()
+        correct += ops.topk_hits(output, target, (1, 5))   # K21 on the GPU, no host sync
         seen += n
         if i % log_interval == 0:
             logger.info(_VAL_MSG.format(t.elapsed, float(loss), i * n))
@@ -205,6 +213,10 @@ def build_data(cfg, device, dtype, logger, world, rank):
         workers = 0 if device.type == "cpu" else cfg.num_workers
         return wrap(_imagenet.make_loader(ds, cfg.batch_size, sampler, workers)), None, len(ds), sampler
     logger.info("Setting up loaders")
+    if not cfg.train_dir:
+        raise ValueError("FAKE is False (the reference's default, imagenet_pytorch_horovod.py:49) and no "
+                         "training directory is set: export AZ_BATCHAI_INPUT_TRAIN / INPUT_TRAIN_DIR, or "
+                         "FAKE=True for synthetic data")
     raw = bool(on_gpu and depth > 0 and getattr(cfg, "uint8_transport", True))
     train_ds = _imagenet.ImageFolder(cfg.train_dir, _imagenet.train_transform(cfg.width, raw_uint8=raw))
     sampler = get_sampler(train_ds, cfg.distributed, seed=cfg.seed)

@@ -16,6 +16,7 @@ import torch
 from .. import torch as hvd
 from ..callbacks import CallbackList
 from ..ops import functional as ops
+from ..utils import trace
 from .loop import to_device_batch
 
 __all__ = ["Trainer"]
@@ -64,17 +65,17 @@ class Trainer:
                 data, target = to_device_batch(data, target, self.device, self.dtype)
                 target = self._labels(target)
                 self.optimizer.zero_grad()
-                out = self.model(data)
-                loss = self.loss_fn(out, target)
-                loss.backward()
-                self.optimizer.step()
+                with trace.range("fwd"):
+                    out = self.model(data)
+                    loss = self.loss_fn(out, target)
+                with trace.range("bwd"):
+                    loss.backward()
+                with trace.range("step"):
+                    self.optimizer.step()
                 with torch.no_grad():
                     n = len(data)
                     loss_sum += loss.detach().double() * n
-                    _, pred = out.detach().float().topk(self.top_k, dim=1)
-                    hit = pred.eq(target.view(-1, 1))
-                    hits[0] += hit[:, :1].any(dim=1).sum()
-                    hits[1] += hit.any(dim=1).sum()
+                    hits += ops.topk_hits(out, target, (1, self.top_k))
                     seen += n
                 cbs.on_batch_end(step, logs)
             seen = max(seen, 1)
@@ -108,10 +109,7 @@ class Trainer:
             out = self.model(data)
             n = len(data)
             loss_sum += self.loss_fn(out, target).double() * n
-            _, pred = out.float().topk(self.top_k, dim=1)
-            hit = pred.eq(target.view(-1, 1))
-            hits[0] += hit[:, :1].any(dim=1).sum()
-            hits[1] += hit.any(dim=1).sum()
+            hits += ops.topk_hits(out, target, (1, self.top_k))
             seen += n
         if was_training:
             self.model.train()

@@ -78,7 +78,7 @@ class TrainConfig:
     batch_size: int = 64  # per GPU (:40)
     seed: int = 42
     distributed: bool = False
-    fake: bool = True
+    fake: bool = False  # reference default (imagenet_pytorch_horovod.py:49)
     fake_data_length: int = IMAGENET_TRAIN_LEN
     validation: bool = False
     train_dir: Optional[str] = None
@@ -108,7 +108,7 @@ class TrainConfig:
             weight_decay=env_float("WEIGHT_DECAY", 0.0),
             warmup_epochs=env_int("WARMUP_EPOCHS", 0),
             distributed=env_bool("DISTRIBUTED", False),
-            fake=env_bool("FAKE", True),
+            fake=env_bool("FAKE", False),
             fake_data_length=env_int("FAKE_DATA_LENGTH", IMAGENET_TRAIN_LEN),
             validation=env_bool("VALIDATION", False),
             train_dir=env_str("AZ_BATCHAI_INPUT_TRAIN", None, "INPUT_TRAIN_DIR"),

@@ -35,17 +35,31 @@ def enabled() -> bool:
     return _load() is not None
 
 
-@contextlib.contextmanager
+class _Range:
+    __slots__ = ("lib", "name")
+
+    def __init__(self, lib, name):
+        self.lib, self.name = lib, name
+
+    def __enter__(self):
+        self.lib.roctxRangePushA(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.roctxRangePop()
+        return False
+
+
+_NULL = contextlib.nullcontext()
+
+
 def range(name: str):  # noqa: A001 - mirrors roctxRange
+    """Context manager: a roctx range around the body (a shared no-op object when disabled, so the
+    training loops call it unconditionally)."""
     lib = _load()
     if lib is None:
-        yield
-        return
-    lib.roctxRangePushA(name.encode())
-    try:
-        yield
-    finally:
-        lib.roctxRangePop()
+        return _NULL
+    return _Range(lib, name.encode())
 
 
 def mark(name: str) -> None:

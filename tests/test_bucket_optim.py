@@ -229,3 +229,33 @@ def test_direct_gradients_are_counted_once_per_backward():
     assert opt._ddl_buckets[0].launched and opt._ddl_buckets[0].pending == 0
     opt.step()
     assert torch.allclose(w1.detach(), torch.full((4,), 0.9)) and torch.allclose(w2.detach(), torch.full((4,), 0.9))
+
+
+def test_freeze_lr_at_zero_keeps_following_the_schedule():
+    """A warm-up starting at lr = 0: the frozen by-value factor must not be 0."""
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    m = torch.nn.Linear(4, 3)
+    opt = FusedSGD(m.named_parameters(), lr=0.0, momentum=0.9)
+    scale = opt.freeze_lr()
+    assert float(scale) == 0.0 and opt._kernel_lr(0.0)[0] == 1.0
+    opt.param_groups[0]["lr"] = 0.25
+    opt.sync_lr()
+    assert float(opt.lr_scale) == 0.25
+    frozen, dev = opt._kernel_lr(0.25)
+    assert frozen * float(dev) == 0.25
+
+
+def test_graph_step_runs_eagerly_when_momentum_is_corrected():
+    from distributeddeeplearning_amd.training.graph import GraphedTrainStep
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    m = torch.nn.Linear(4, 3)
+    opt = FusedSGD(m.named_parameters(), lr=0.1, momentum=0.9)
+    gs = GraphedTrainStep(m, opt, lambda o, y: o.sum())
+    before = gs._hyper()
+    opt.param_groups[0]["momentum"] = 0.45   # what LearningRateScheduleCallback does for one step
+    assert gs._hyper() != before
+    opt.param_groups[0]["momentum"] = 0.9
+    opt.param_groups[0]["lr"] = 0.5           # the learning rate alone does not force eager steps
+    assert gs._hyper() == before
