@@ -33,7 +33,10 @@ struct IGemmParams {
     bf16_t* y;
     const bf16_t* addend;  // optional [M][N], added in the epilogue
     float* stats;          // optional [tilesM][2][N] partial sums of y and y^2 (bf16-rounded y)
-    unsigned x_bytes, w_bytes;
+    long long x_bytes;     // whole input tensor; every workgroup addresses it relative to its first image (32-bit offsets)
+    unsigned w_bytes;
+    int wt_rows;           // WT: reduction rows (forward output channels) the weight tensor really has (<= C)
+    int wt;                // backward-data reads the FORWARD weights w[k][r][s][n] ("KRSC", n contiguous) through transposing LDS reads
     int Hin, Win, C;       // input image (logical, before dilation) and reduction channels
     long long xs_b, xs_h, xs_w;  // element strides of the input
     int Hout, Wout, N, M;
@@ -75,9 +78,19 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 #ifndef DDL_CONV_MIN_WAVES
 #define DDL_CONV_MIN_WAVES 2   // waves per SIMD the register allocation must allow (3 and 4 measured: profiles/r1_notes.md)
 #endif
-template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS>
+// swizzle of the transposed weight image (WT): 32-byte window w of reduction row r is stored at
+// window w ^ wt_swz(r), so that the 8 rows a half-wave's transposing read touches ({8g+q}, g in
+// {0,1} or {2,3}, q = 0..3, and the same +4) fall into 8 distinct 32-byte windows of a bank row
+template <int ROW_BYTES>
+__device__ __forceinline__ int wt_swz(int row) {
+    return ROW_BYTES == 256 ? ((row & 3) | ((row >> 1) & 4)) : (((row >> 1) & 1) | ((row >> 2) & 2));
+}
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS, bool WT = false>
 __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WAVES : 2) conv_igemm_kernel(const IGemmParams p) {
     static_assert(BM % 128 == 0, "statistics rows are per 128 output rows");
+    static_assert(!WT || (GLDS && EPI != 1), "the transposed weight image is an LDS-DMA image; forward statistics never use it");
     constexpr bool STATS = EPI == 1 || EPI == 2 || EPI == 4;
     constexpr int CPR = BK / 8;            // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;         // rows covered per pass of the 256 threads
@@ -130,7 +143,16 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
     const int tstep = p.parity ? 2 : 1;
     const int r0 = p.parity ? ((p.pad + ph) & 1) : 0, s0 = p.parity ? ((p.pad_w + pw) & 1) : 0;
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    // Tensors beyond 2 GiB: the buffer descriptor starts at the first image this tile touches
+    // (plain GEMM: at the tile's first row), so the 32-bit offsets only span one tile's images.
+    const int Wq = p.parity ? (p.Wout >> 1) : p.Wout;
+    const int hw = p.parity ? (p.Hout >> 1) * Wq : p.Hout * p.Wout;
+    const int b_lo = p.simple ? 0 : m0 / hw;
+    const long long x_first = p.simple ? (long long)m0 * p.xs_w : (long long)b_lo * p.xs_b;   // elements
+    long long x_left = p.x_bytes - x_first * 2;
+    if (x_left < 0) x_left = 0;
+    if (x_left > 0x7fffffffLL) x_left = 0x7fffffffLL;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + x_first), 0, (int)x_left, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 
     // GLDS (operand tiles by LDS-DMA, `buffer_load_dwordx4 ... lds`): a wave-instruction writes
@@ -141,34 +163,47 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
     const int ch = !GLDS ? chp : (BK == 64 ? (chp ^ (row0 & 7)) : (chp ^ ((0 - (row0 >> 2)) & 3)));
     const int Kdim = p.R * p.S * p.C;
     // per-row A state
-    long long a_base[A_LOADS];
+    int a_base[A_LOADS];   // element offset from x_first
     int a_h0[A_LOADS], a_w0[A_LOADS];
-    const int Wq = p.parity ? (p.Wout >> 1) : p.Wout;
-    const int hw = p.parity ? (p.Hout >> 1) * Wq : p.Hout * p.Wout;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         int m = m0 + row0 + i * RPP;
         if (p.simple) {  // plain GEMM: 36 of ResNet-50's 53 convs; saves the two integer divisions per row
             a_h0[i] = m < m_lim ? 0 : -(1 << 28);
             a_w0[i] = 0;
-            a_base[i] = (long long)m * p.xs_w + ch * 8;
+            a_base[i] = (row0 + i * RPP) * (int)p.xs_w + ch * 8;
         } else if (m < m_lim) {
             int b = m / hw, rem = m - b * hw;
             int ho = rem / Wq, wo = rem - ho * Wq;
             if (p.parity) { ho = 2 * ho + ph; wo = 2 * wo + pw; }
             a_h0[i] = ho * p.ostride - p.pad;
             a_w0[i] = wo * p.ostride - p.pad_w;
-            a_base[i] = (long long)b * p.xs_b + ch * 8;
+            a_base[i] = (b - b_lo) * (int)p.xs_b + ch * 8;
         } else {
             a_h0[i] = -(1 << 28); a_w0[i] = 0; a_base[i] = 0;  // never valid
         }
     }
     unsigned b_off[B_LOADS];
+    unsigned b_off_last[WT ? B_LOADS : 1];   // WT: the same for the last reduction tile, rows past the weight's end masked
+    constexpr int WROW = BN * 2;        // WT: bytes per reduction row of the [BK][BN] weight image
+    constexpr int WCPR = BN / 8;        //     16-byte chunks per row
+    const int RSN = p.R * p.S * p.N;    // WT: elements between consecutive reduction channels of w[k][r][s][n]
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-        int n = n0 + row0 + i * RPP;
-        long long o = ((long long)n * Kdim + ch * 8) * 2;
-        b_off[i] = (n < p.N && o < 0x7fffffffLL) ? (unsigned)o : 0x80000000u;
+        if (WT) {
+            // slot idx of the dense image: row = reduction channel inside the tile, physical chunk
+            // position -> logical chunk (the windows are swizzled on the SOURCE side, like the A tile)
+            const int idx = tid + i * 256, row = idx / WCPR, chq = idx - row * WCPR;
+            const int lch = (((chq >> 1) ^ wt_swz<WROW>(row)) << 1) | (chq & 1);
+            const int n = n0 + lch * 8;
+            b_off[i] = n < p.N ? (unsigned)((row * RSN + n) * 2) : 0x80000000u;
+            // (the scalar offset that selects the reduction tile is not range-checked by the hardware)
+            b_off_last[i] = (p.C - BK + row < p.wt_rows) ? b_off[i] : 0x80000000u;
+        } else {
+            int n = n0 + row0 + i * RPP;
+            long long o = ((long long)n * Kdim + ch * 8) * 2;
+            b_off[i] = (n < p.N && o < 0x7fffffffLL) ? (unsigned)o : 0x80000000u;
+        }
     }
 
     const int idil_mask = (1 << p.idil_log2) - 1;
@@ -191,7 +226,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
             bool ok = (th >= 0) & (tw >= 0) & (((th | tw) & idil_mask) == 0);
             int hi = th >> p.idil_log2, wi = tw >> p.idil_log2;
             ok = ok & (hi < p.Hin) & (wi < p.Win);
-            a_voff[i] = ok ? (unsigned)((int)(a_base[i] * 2) + hi * xs_h2 + wi * xs_w2) : INVALID;
+            a_voff[i] = ok ? (unsigned)(a_base[i] * 2 + hi * xs_h2 + wi * xs_w2) : INVALID;
         }
     };
     auto fetch = [&](u32x4 (&ar)[A_LOADS], u32x4 (&br)[B_LOADS]) {
@@ -226,10 +261,14 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(As + i * RPP * (BK * 2)), 16, (int)a_voff[i], kco, 0, 0);
-        const int wk = ((kr * p.S + ks) * p.C + kc * BK) * 2;
+        // WT: tap (kr, ks) of the backward conv is tap (R-1-kr, S-1-ks) of the forward filter
+        const int wk = WT ? (kc * BK * RSN + ((p.R - 1 - kr) * p.S + (p.S - 1 - ks)) * p.N) * 2
+                          : ((kr * p.S + ks) * p.C + kc * BK) * 2;
+        const bool wlast = WT && kc == cpt - 1;   // uniform
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(Bs + i * RPP * (BK * 2)), 16, (int)b_off[i], wk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(Bs + i * RPP * (BK * 2)), 16,
+                                                     (int)(wlast ? b_off_last[WT ? i : 0] : b_off[i]), wk, 0, 0);
         if (++kc == cpt) { kc = 0; ks += tstep; if (ks >= p.S) { ks = s0; kr += tstep; } }
     };
 
@@ -261,9 +300,24 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
 #pragma unroll
             for (int j = 0; j < FM; ++j)
                 xa[j] = *reinterpret_cast<const bf16x8*>(As + lds_off<BK>(wm * WM + j * 16 + fr, kk * 4 + fq));
+            if (WT) {
+                // transposing read: lane 16g + 4q + pq supplies reduction row 8g + q (+4), columns 4pq..4pq+3 of
+                // the 16-channel window; lane i of the group receives channel i with 4 consecutive reduction rows
+                const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+                const int trow = kk * 32 + 8 * tg + tq;
+                const int tswz = wt_swz<WROW>(trow);
+#pragma unroll
+                for (int i = 0; i < FN; ++i) {
+                    unsigned char* b0 = const_cast<unsigned char*>(Bs) + trow * WROW + (((((wn * WN) >> 4) + i) ^ tswz) << 5) + 8 * tp;
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(b0));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(b0 + 4 * WROW));
+                    wb[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < FN; ++i)
                 wb[i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<BK>(wn * WN + i * 16 + fr, kk * 4 + fq));
+            }
             }
 #ifdef DDL_CONV_PROBES
             if (p.probe & 4) {
@@ -517,19 +571,22 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
 #endif
 }
 
-template <int BM, int BN, int BK, bool GLDS>
+template <int BM, int BN, int BK, bool GLDS, bool WT>
 int launch_cfg2(const IGemmParams& p, hipStream_t stream) {
     dim3 grid(p.tiles_m * p.tiles_n), block(256);
     static const int extra_lds = getenv("DDL_CONV_EXTRA_LDS") ? atoi(getenv("DDL_CONV_EXTRA_LDS")) : 0;  // occupancy probe
     const bool mask = p.ep_mask || p.ep_maskbits;
     if (p.stats && p.addend && !(p.ep_y && mask)) return DDL_EINVAL;
-#define DDL_LAUNCH(E, A) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, E, A, GLDS>), grid, block, extra_lds, stream, p)
+#define DDL_LAUNCH(E, A) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, E, A, GLDS, WT>), grid, block, extra_lds, stream, p)
     if (p.ep_y && mask && p.addend) DDL_LAUNCH(4, true);
     else if (p.ep_y && mask) DDL_LAUNCH(4, false);
     else if (p.ep_y) DDL_LAUNCH(2, false);
     else if (mask && p.addend) DDL_LAUNCH(3, true);
     else if (mask) DDL_LAUNCH(3, false);
-    else if (p.stats) DDL_LAUNCH(1, false);
+    else if (p.stats) {
+        if constexpr (WT) return DDL_EINVAL;   // forward statistics belong to the forward weight layout
+        else DDL_LAUNCH(1, false);
+    }
     else if (p.addend) DDL_LAUNCH(0, true);
     else DDL_LAUNCH(0, false);
 #undef DDL_LAUNCH
@@ -543,7 +600,8 @@ int launch_cfg(const IGemmParams& p, hipStream_t stream) {
     // 3.47 -> 3.28 ms, the BK=64 tiles gain most (d4 3x3 512 @7: 78 -> 61 us = 974 TFLOP/s).
     // DDL_CONV_GLDS=0 selects the register-staged path (global -> VGPR -> ds_write_b128).
     static const int glds = getenv("DDL_CONV_GLDS") ? atoi(getenv("DDL_CONV_GLDS")) : 1;  // tuning knob
-    return glds ? launch_cfg2<BM, BN, BK, true>(p, stream) : launch_cfg2<BM, BN, BK, false>(p, stream);
+    if (p.wt) return launch_cfg2<BM, BN, BK, true, true>(p, stream);   // transposed weight image: LDS-DMA only
+    return glds ? launch_cfg2<BM, BN, BK, true, false>(p, stream) : launch_cfg2<BM, BN, BK, false, false>(p, stream);
 }
 
 }  // namespace
@@ -565,18 +623,31 @@ extern "C" int ddl_conv_igemm_tiles_m_bwd(long long M, int Hout, int Wout, int i
     return (int)((M + 127) / 128);
 }
 
-extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const void* addend, void* stats,
+// `wt` = 1: `w` is the FORWARD filter w[k][r][s][n] of the convolution whose input gradient this
+// launch computes (C = its output channels k, N = its input channels n); the kernel reads it through
+// transposing LDS loads, so no flipped/transposed copy of the weights exists anywhere.
+extern "C" int ddl_conv_igemm_ex3(const void* x, const void* w, void* y, const void* addend, void* stats,
                                   long long x_numel, long long w_numel,
                                   int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
                                   int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
                                   int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
-                                  const void* ep_y2, void* stats2, const void* ep_maskbits, hipStream_t stream) {
+                                  const void* ep_y2, void* stats2, const void* ep_maskbits, int wt, int wt_rows,
+                                  hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || N <= 0 || R <= 0 || S <= 0) return DDL_EINVAL;
     if (C % 32 != 0 || N % 8 != 0) return DDL_EINVAL;
     if (idil != 1 && idil != 2 && idil != 4) return DDL_EINVAL;
     if (ostride <= 0 || pad < 0 || pad_w < 0 || Hout <= 0 || Wout <= 0) return DDL_EINVAL;
-    if (x_numel * 2 >= 0x7fffffffLL || w_numel * 2 >= 0x7fffffffLL) return DDL_EINVAL;
-    if (w_numel < (long long)N * R * S * C) return DDL_EINVAL;
+    if (x_numel <= 0 || w_numel * 2 >= 0x7fffffffLL) return DDL_EINVAL;
+    if (!wt && w_numel < (long long)N * R * S * C) return DDL_EINVAL;
+    if (wt && (wt_rows <= 0 || wt_rows > C || wt_rows <= C - 32 || w_numel < (long long)N * R * S * wt_rows)) return DDL_EINVAL;
+    if (wt && (stats && !ep_y)) return DDL_EINVAL;
+    // 32-bit offsets are relative to the first image a tile touches: a tile of <= 256 output rows
+    // spans at most 256 / (Hout*Wout) + 2 images (tensors themselves may exceed 2 GiB)
+    {
+        long long hw_min = (long long)Hout * Wout / 4;   // a parity class holds a quarter of the image's pixels
+        if (hw_min < 1) hw_min = 1;
+        if ((256 / hw_min + 3) * xs_b * 2 >= 0x7fffffffLL || 257 * xs_w * 2 >= 0x7fffffffLL) return DDL_EINVAL;
+    }
     if (!ddl_aligned16(x) || !ddl_aligned16(w) || !ddl_aligned16(y) || (addend && !ddl_aligned16(addend))) return DDL_EALIGN;
     if ((ep_y && !ddl_aligned16(ep_y)) || (ep_fcoef && !ddl_aligned16(ep_fcoef)) || (ep_mask && !ddl_aligned16(ep_mask))) return DDL_EALIGN;
     // fused BatchNorm-backward reduce needs y, the forward coefficients and the partial buffer together
@@ -605,7 +676,9 @@ extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const v
     p.ep_y = (const bf16_t*)ep_y; p.ep_fcoef = (const float*)ep_fcoef; p.ep_mask = (const bf16_t*)ep_mask;
     p.ep_y2 = (const bf16_t*)ep_y2; p.stats2 = (float*)stats2;
     p.ep_maskbits = (const unsigned char*)ep_maskbits;
-    p.x_bytes = (unsigned)(x_numel * 2); p.w_bytes = (unsigned)(w_numel * 2);
+    p.x_bytes = x_numel * 2; p.w_bytes = (unsigned)(w_numel * 2);
+    p.wt = wt ? 1 : 0;
+    p.wt_rows = wt ? wt_rows : C;
     // timing-only probe (results are wrong): a descriptor with zero records drops every load through
     // it while the instruction stream, waits and barriers stay - prices one operand's traffic
     static const int probe = getenv("DDL_CONV_PROBE") ? atoi(getenv("DDL_CONV_PROBE")) : 0;
@@ -664,6 +737,17 @@ extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const v
         return launch_cfg<256, 128, 32>(p, stream);  // (a BK=64 twin needs 96 KB of LDS: one workgroup per CU, 15-30 % slower)
     }
     return deep ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
+}
+
+extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const void* addend, void* stats,
+                                  long long x_numel, long long w_numel,
+                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                  int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
+                                  int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
+                                  const void* ep_y2, void* stats2, const void* ep_maskbits, hipStream_t stream) {
+    return ddl_conv_igemm_ex3(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
+                              N, R, S, ostride, pad, pad_w, idil, addend_sub2, ep_y, ep_fcoef, ep_mask, ep_y2, stats2,
+                              ep_maskbits, 0, 0, stream);
 }
 
 extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const void* addend, void* stats,

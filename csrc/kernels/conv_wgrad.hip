@@ -23,27 +23,19 @@ struct WgradParams {
     const bf16_t* dy;
     const bf16_t* x;
     float* partial;  // [splits][K][RSC]
-    unsigned dy_bytes, x_bytes;
+    long long dy_bytes, x_bytes;   // whole tensors (may exceed 2 GiB): every split addresses them relative to its first row / image
     int Hin, Win, C;
     long long xs_b, xs_h, xs_w;
     int Hout, Wout, K, M;
     int R, S, stride, pad, pad_w;
     int tiles_k, tiles_rsc, splits, m_per_split;  // tiles over K and over the flattened (r, s, c) axis
     int simple;  // x row of pixel m is x + m*xs_w (1x1, stride 1, no padding)
-    float inv_hw, inv_w;
 };
 
 __device__ __forceinline__ u32x4 wg_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0);
 }
 
-// q = m / d, r = m % d for 0 <= m < 2^24 through an fp32 reciprocal and a one-step fix-up
-__device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r) {
-    q = (int)((float)m * inv);
-    r = m - q * d;
-    if (r >= d) { ++q; r -= d; }
-    if (r < 0) { --q; r += d; }
-}
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
@@ -94,14 +86,22 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     if (m_end > p.M) m_end = p.M;
     const int KT = (m_end - m_begin + BK - 1) / BK;
 
-    const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    // Tensors beyond 2 GiB: the descriptors start at this split's first reduction row (dy; x of a
+    // plain GEMM) or first image (x), so 32-bit offsets only span one split.
+    const int hw = p.Hout * p.Wout;
+    const int b_first = m_begin / hw;
+    const long long dy_first = (long long)m_begin * p.K;
+    const long long x_first = SIMPLE ? (long long)m_begin * p.xs_w : (long long)b_first * p.xs_b;
+    long long dy_left = p.dy_bytes - dy_first * 2, x_left = p.x_bytes - x_first * 2;
+    dy_left = dy_left < 0 ? 0 : (dy_left > 0x7fffffffLL ? 0x7fffffffLL : dy_left);
+    x_left = x_left < 0 ? 0 : (x_left > 0x7fffffffLL ? 0x7fffffffLL : x_left);
+    const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + dy_first), 0, (int)dy_left, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + x_first), 0, (int)x_left, 0x00020000);
 
     // Per-thread load slots are fixed over the whole reduction: (row, chunk) never change and the
     // pixel index only advances by BK per tile.  dy offsets therefore ride in the buffer
     // instruction's scalar offset; the (b, ho, wo) decomposition of the x row is computed once
     // and then stepped (no divisions and no 64-bit arithmetic in the loop).
-    const int hw = p.Hout * p.Wout;
     u32x4 a_reg[A_LOADS], b_reg[B_LOADS];
     constexpr unsigned INVALID = 0x80000000u;
     unsigned a_voff[A_LOADS];
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
         int row = idx / A_CPR, ch = idx - row * A_CPR;
         if (GLDS) ch = (((ch >> 1) ^ lds_swz<BMw * 2>(row)) << 1) | (ch & 1);  // physical position -> logical chunk
         int n = n0 + ch * 8;
-        a_voff[i] = (row < BK && n < p.K) ? ((unsigned)(m_begin + row) * (unsigned)p.K + (unsigned)n) * 2u : INVALID;
+        a_voff[i] = (row < BK && n < p.K) ? ((unsigned)row * (unsigned)p.K + (unsigned)n) * 2u : INVALID;
     }
     int b_wo[B_LOADS], b_ho[B_LOADS], b_dh[B_LOADS], b_dw[B_LOADS];
     unsigned b_base[B_LOADS];  // byte offset of (b, hi = ho*stride - pad + r, wi = 0, c)
@@ -129,15 +129,15 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
         b_dw[i] = fs - p.pad_w;
         int m = m_begin + row;
         if (SIMPLE) {
-            b_base[i] = live ? ((unsigned)m * (unsigned)p.xs_w + (unsigned)c) * 2u : INVALID;
+            b_base[i] = live ? ((unsigned)row * (unsigned)p.xs_w + (unsigned)c) * 2u : INVALID;
             b_wo[i] = 0; b_ho[i] = 0;
         } else {
-            int b, rem, ho, wo;
-            fdivmod(m, hw, p.inv_hw, b, rem);
-            fdivmod(rem, p.Wout, p.inv_w, ho, wo);
+            // once per thread and slot: exact integer divisions (an fp32 reciprocal is only exact below 2^24 rows)
+            const int b = m / hw, rem = m - b * hw;
+            const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
             b_wo[i] = wo;
             b_ho[i] = live ? ho : -(1 << 24);   // a dead slot never passes the hi >= 0 test
-            b_base[i] = (unsigned)((b * (int)p.xs_b + (ho * p.stride + fr - p.pad) * (int)p.xs_h + c) * 2);
+            b_base[i] = (unsigned)(((b - b_first) * (int)p.xs_b + (ho * p.stride + fr - p.pad) * (int)p.xs_h + c) * 2);
         }
     }
     const int step_w = BK % p.Wout, step_h = BK / p.Wout;         // BK pixels = step_h rows + step_w
@@ -397,19 +397,19 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
                               hipStream_t stream) {
     if (!dy || !x || !partial || B <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || splits <= 0) return DDL_EINVAL;
     if (C % 8 != 0 || K % 8 != 0) return DDL_EINVAL;
-    if (dy_numel * 2 >= 0x7fffffffLL || x_numel * 2 >= 0x7fffffffLL) return DDL_EINVAL;
+    if (dy_numel <= 0 || x_numel <= 0) return DDL_EINVAL;
     if (!ddl_aligned16(dy) || !ddl_aligned16(x) || !ddl_aligned16(partial)) return DDL_EALIGN;
     if ((xs_b % 8) || (xs_h % 8)) return DDL_EALIGN;
     if (xs_w % 8) {
         if (S != 1 || ((long long)stride * xs_w) % 8 || ((long long)pad_w * xs_w) % 8) return DDL_EALIGN;
     }
     long long M = (long long)B * Hout * Wout;
-    if (M >= (1LL << 24) || dy_numel < M * K) return DDL_EINVAL;
+    if (M >= (1LL << 31) - 4096 || dy_numel < M * K) return DDL_EINVAL;
     long long last = (long long)(B - 1) * xs_b + (long long)(Hin - 1) * xs_h + (long long)(Win - 1) * xs_w + C;
     if (last > x_numel) return DDL_EINVAL;
     WgradParams p;
     p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.partial = (float*)partial;
-    p.dy_bytes = (unsigned)(dy_numel * 2); p.x_bytes = (unsigned)(x_numel * 2);
+    p.dy_bytes = dy_numel * 2; p.x_bytes = x_numel * 2;
     p.Hin = Hin; p.Win = Win; p.C = C; p.xs_b = xs_b; p.xs_h = xs_h; p.xs_w = xs_w;
     p.Hout = Hout; p.Wout = Wout; p.K = K; p.M = (int)M;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.pad_w = pad_w;
@@ -417,10 +417,11 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
     long long mps = (M + splits - 1) / splits;
     mps = (mps + 31) / 32 * 32;
     p.m_per_split = (int)mps;
+    // 32-bit offsets inside one split: its dy rows, and the images its x rows come from
+    if ((mps + 64) * K * 2 >= 0x7fffffffLL) return DDL_EINVAL;
+    if ((mps / ((long long)Hout * Wout) + 3) * xs_b * 2 >= 0x7fffffffLL || (mps + 64) * xs_w * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0 && pad_w == 0 && Hin == Hout && Win == Wout &&
                 xs_h == (long long)Win * xs_w && xs_b == (long long)Hin * xs_h) ? 1 : 0;
-    p.inv_hw = 1.0f / (float)(Hout * Wout);
-    p.inv_w = 1.0f / (float)Wout;
     int bm, bn;
     wgrad_tile(K, C, R, S, bm, bn);
     if (bm == 64) {

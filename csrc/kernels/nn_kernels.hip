@@ -655,15 +655,16 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight flip-transpose for backward-data, many tensors per launch:
+// Weight flip-transpose for backward-data, all tensors in one launch:
 //   dst[c][R-1-r][S-1-s][k] = src[k][r][s][c]   (k padded with zeros up to Kpad)
-// One block moves a 32(k) x 32(c) tile of one tap through LDS.
+// One block moves a 64(k) x 64(c) tile of one tap through LDS with 16-byte global accesses on
+// both sides (25.5 M elements of ResNet-50 per optimizer step: ~100 MB of traffic).
 // ---------------------------------------------------------------------------------------------
 struct WtEntry { long long src, dst; int K, R, S, C, Kpad, block0; };
 
 __global__ void __launch_bounds__(256) weight_flip_transpose_kernel(const bf16_t* __restrict__ base_src, bf16_t* __restrict__ base_dst,
                                                                    const WtEntry* __restrict__ table, int nentries) {
-    __shared__ bf16_t tile[32][34];
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];   // 144-byte rows: 16-byte aligned, 36 banks apart
     int lo = 0, hi = nentries - 1;
     const int bid = blockIdx.x;
     while (lo < hi) {
@@ -672,29 +673,37 @@ __global__ void __launch_bounds__(256) weight_flip_transpose_kernel(const bf16_t
     }
     const WtEntry e = table[lo];
     int t = bid - e.block0;
-    const int ct = (e.C + 31) / 32, kt = (e.Kpad + 31) / 32;
+    const int ct = (e.C + 63) / 64, kt = (e.Kpad + 63) / 64;
     const int tc = t % ct; t /= ct;
     const int tk = t % kt; t /= kt;
     const int s = t % e.S, r = t / e.S;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const bf16_t* src = base_src + e.src;
     bf16_t* dst = base_dst + e.dst;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int k = tk * 32 + ty + i * 8, c = tc * 32 + tx;
-        bf16_t v = f2bf(0.f);
-        if (k < e.K && c < e.C) v = src[(((long long)k * e.R + r) * e.S + s) * e.C + c];
-        tile[ty + i * 8][tx] = v;
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + i * 256, row = idx >> 3, chn = idx & 7;
+        const int k = tk * 64 + row, c = tc * 64 + chn * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f2bf(0.f);
+        if (k < e.K && c < e.C) v = *reinterpret_cast<const bf16x8*>(src + (((long long)k * e.R + r) * e.S + s) * e.C + c);
+        *reinterpret_cast<bf16x8*>(&tile[row][chn * 8]) = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = tc * 32 + ty + i * 8, k = tk * 32 + tx;
-        if (c < e.C && k < e.Kpad)
-            dst[(((long long)c * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)) * e.Kpad + k] = tile[tx][ty + i * 8];
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + i * 256, crow = idx >> 3, kch = idx & 7;
+        const int c = tc * 64 + crow, k0 = tk * 64 + kch * 8;
+        if (c < e.C && k0 < e.Kpad) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[kch * 8 + j][crow];
+            *reinterpret_cast<bf16x8*>(dst + (((long long)c * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)) * e.Kpad + k0) = v;
+        }
     }
 }
 
+// ---------------------------------------------------------------------------------------------
 // Stem input packing: NHWC (C <= 4) bf16 -> [B][H][W + 8][4] with 3 zero pixels on the left, 5 on
 // the right and zero-filled extra channels, so one filter row of the 7x7/2 stem conv is one
 // contiguous, 16-byte-aligned 64-byte run (8 taps x 4 channels) for every output column.

@@ -67,6 +67,8 @@ class _WeightTransposes:
         self.dst = None
         self.total_blocks = 0
         self.base_src = 0
+        self.pending = None     # event of a refresh running on the weight-gradient stream
+        self.captured_epoch = -1
 
     def bump(self):
         self.epoch += 1
@@ -92,7 +94,9 @@ class _WeightTransposes:
         off = blocks = 0
         for i, e in enumerate(ents):
             e["dst_off"] = off
-            nb = ((e["Kpad"] + 31) // 32) * ((e["C"] + 31) // 32) * e["R"] * e["S"]
+            nb = ((e["Kpad"] + 63) // 64) * ((e["C"] + 63) // 64) * e["R"] * e["S"]   # 64 x 64 tiles per tap
+            if e["C"] % 8 or (e["ptr"] - self.base_src) % 16:
+                raise K.KernelError("weight transposition needs 16-byte aligned weights with channels % 8 == 0")
             tab[i] = ((e["ptr"] - self.base_src) // 2, off, e["K"], e["R"], e["S"], e["C"],
                       e["Kpad"], blocks)
             blocks += nb
@@ -103,31 +107,72 @@ class _WeightTransposes:
         self.n = len(ents)
         self.dirty = False
 
+    def _launch(self):
+        K.weight_flip_transpose(self.base_src, self.dst.data_ptr(), self.table, self.n, self.total_blocks)
+        for x in self.entries.values():
+            x["version"] = x["w"]._version
+        self.done_epoch = self.epoch
+
+    def refresh_async(self):
+        """Called right after an optimizer step: transpose on the weight-gradient stream, which is
+        idle during the forward pass, instead of in front of the first backward-data kernel (the
+        launch sat on the critical path of backward: ~0.13 ms per ResNet-50 step)."""
+        if self.dirty or self.table is None or not _SIDE["on"] or _WT_KRSC:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        side = _side_stream(self.dst.device)
+        side.wait_stream(torch.cuda.current_stream(self.dst.device))   # after the optimizer's writes
+        with torch.cuda.stream(side):
+            self._launch()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.pending = ev
+
     def get(self, w):
         e = self.entries.get(id(w))
         if e is None or e["ptr"] != w.data_ptr():
             self._register(w)
             e = self.entries[id(w)]
+        if self.pending is not None:   # first use after an asynchronous refresh: order this stream behind it
+            torch.cuda.current_stream().wait_event(self.pending)
+            self.pending = None
         stale = self.dirty or self.done_epoch != self.epoch or e["version"] != w._version
+        if not stale and self.captured_epoch != self.epoch and torch.cuda.is_current_stream_capturing():
+            # a step being captured into a HIP graph must contain its own refresh: the replays never
+            # come through here, and the asynchronous refresh above ran outside the graph
+            stale = True
+            self.captured_epoch = self.epoch
         if self.dirty:
             self._rebuild(w.device)
         if stale:
-            K.weight_flip_transpose(self.base_src, self.dst.data_ptr(), self.table, self.n,
-                                    self.total_blocks)
-            for x in self.entries.values():
-                x["version"] = x["w"]._version
-            self.done_epoch = self.epoch
+            self._launch()
         n = e["C"] * e["R"] * e["S"] * e["Kpad"]
         return self.dst[e["dst_off"]: e["dst_off"] + n]
 
 
 _WT = _WeightTransposes()
+import os as _os0
+# DDL_DGRAD_KRSC=1: backward-data reads the FORWARD filter and transposes it with ds_read_b64_tr_b16 on
+# the way from LDS to the matrix cores (no transposed copy, no transposition kernel).  Measured 0.4 ms
+# per ResNet-50 step SLOWER than the copy (twice the LDS read instructions for the weight operand at
+# 2-3 waves per SIMD, profiles/r2_notes.md), so the default keeps the copy, refreshed once per step
+# on the weight-gradient stream during the forward pass.
+_WT_KRSC = _os0.environ.get("DDL_DGRAD_KRSC", "0") == "1"
+
+
+def _dgrad_w(w):
+    """(weight operand, wt_rows) of a backward-data launch."""
+    if _WT_KRSC:
+        return w, w.shape[0]
+    return _WT.get(w), 0
 
 
 def weights_changed():
     """Tell the transposed-weight cache that parameters were updated outside autograd's view
     (the fused optimizers write them through raw pointers)."""
     _WT.bump()
+    _WT.refresh_async()
 
 
 def reset_caches():
@@ -255,7 +300,7 @@ def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False,
     ``mask_src`` when given."""
     B, C, H, W = x_shape
     _, _, R, S = w.shape
-    wt = _WT.get(w)
+    wt, wrows = _dgrad_w(w)
     if R == 1 and S == 1 and stride == 2 and padding == 0 and addend is None and mask_src is None:
         # 1x1 stride 2: only even pixels receive a gradient; compute them as a plain GEMM and
         # scatter (the fused block never gets here: it hands the compact result to the next
@@ -274,7 +319,7 @@ def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False,
                  addend=addend, addend_sub2=addend_sub2,
                  ep_mask=mask_src if mask_bits is None else None, ep_y=bn_y,
                  stats=partial, ep_y2=bn_y2 if bn_y is not None else None, stats2=partial2,
-                 ep_maskbits=mask_bits if mask_src is not None else None)
+                 ep_maskbits=mask_bits if mask_src is not None else None, wt_rows=wrows)
     if bn_y is None:
         return dx
     return (dx, partial) if bn_y2 is None else (dx, partial, partial2)
@@ -286,12 +331,12 @@ def _conv_dgrad_bn(dy, w, x_shape, stride, padding, y_prev, fcoef_prev):
     pass of that BatchNorm's backward (K8a) rides in the epilogue.  Returns (g, partial)."""
     B, C, H, W = x_shape
     _, _, R, S = w.shape
-    wt = _WT.get(w)
+    wt, wrows = _dgrad_w(w)
     T = K.conv_tiles_m_bwd(B * H * W, H, W, stride, 1)
     partial = torch.empty((T, 2, C), dtype=torch.float32, device=dy.device)
     g = _empty_nhwc(B, C, H, W, dy.device)
     K.conv_igemm(dy, _geom(dy), wt, g, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
-                 stats=partial, ep_y=y_prev, ep_fcoef=fcoef_prev)
+                 stats=partial, ep_y=y_prev, ep_fcoef=fcoef_prev, wt_rows=wrows)
     return g, partial
 
 
@@ -299,9 +344,9 @@ def _conv_dgrad_1x1s2_compact(dy, w):
     """Gradient of a 1x1 / stride 2 conv at the even input pixels only: [B, Cin, Ho, Wo]."""
     B, Kc, Ho, Wo = dy.shape
     C = w.shape[1]
-    wt = _WT.get(w)
+    wt, wrows = _dgrad_w(w)
     out = _empty_nhwc(B, C, Ho, Wo, dy.device)
-    K.conv_igemm(dy, _geom(dy), wt, out, C, 1, 1, 1, 0, 0, 1, Ho, Wo)
+    K.conv_igemm(dy, _geom(dy), wt, out, C, 1, 1, 1, 0, 0, 1, Ho, Wo, wt_rows=wrows)
     return out
 
 
@@ -1193,9 +1238,9 @@ class LinearFn(Function):
         dx = dw = db = None
         gy = (B, 1, 1, npad, npad, npad, npad, dyp.numel())
         if ctx.needs_input_grad[0]:
-            wt = _WT.get(w)
+            wt, wrows = _dgrad_w(w)
             dx = torch.empty((B, C), dtype=_BF16, device=dy.device)
-            K.conv_igemm(dyp, gy, wt, dx, C, 1, 1, 1, 0, 0, 1, 1, 1)
+            K.conv_igemm(dyp, gy, wt, dx, C, 1, 1, 1, 0, 0, 1, 1, 1, wt_rows=wrows)
         if ctx.needs_input_grad[1]:
             gx = (B, 1, 1, C, C, C, C, x.numel())
             dw = _wgrad_into(dyp, x, gx, torch.empty_like(w), npad, 1, 1, 1, 0, 0, 1, 1,

@@ -225,8 +225,11 @@ def storage_numel_from(x):
 
 def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil, Hout, Wout,
                addend=None, stats=None, addend_sub2=False, ep_y=None, ep_fcoef=None, ep_mask=None,
-               ep_y2=None, stats2=None, ep_maskbits=None):
+               ep_y2=None, stats2=None, ep_maskbits=None, wt_rows=0):
     """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel).
+
+    ``wt_rows`` > 0: backward-data mode - ``w`` is the FORWARD filter ``[wt_rows][R][S][n_out]`` and
+    the kernel transposes it on the way from LDS to the matrix cores (no transposed copy exists).
 
     Fused backward epilogues: ``ep_y`` + ``ep_fcoef`` (+ ``stats``) store the gradient masked by
     the ReLU of ``bn(ep_y)`` and emit the BatchNorm-backward partial sums per tile; ``ep_mask``
@@ -249,11 +252,11 @@ def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil,
         raise KernelError("conv_igemm: second partial buffer missing or too small")
     if ep_maskbits is not None and (ep_mask is not None or ep_maskbits.numel() * 8 < y.numel()):
         raise KernelError("conv_igemm: ep_maskbits excludes ep_mask and must cover the output")
-    f = _fn("ddl_conv_igemm_ex2", "ppppp qq iiii qqq iiiiiiiiii ppppppp")
+    f = _fn("ddl_conv_igemm_ex3", "ppppp qq iiii qqq iiiiiiiiii pppppp ii p")
     check(f(x_ptr_tensor.data_ptr(), _p(w), y.data_ptr(), _p(addend), _p(stats), xn,
             w.numel(), B, Hin, Win, C, sb, sh, sw, Hout, Wout, n_out, R, S, ostride, pad, pad_w, idil,
             1 if addend_sub2 else 0, _p(ep_y), _p(ep_fcoef), _p(ep_mask), _p(ep_y2), _p(stats2),
-            _p(ep_maskbits), _raw_stream()),
+            _p(ep_maskbits), 1 if wt_rows else 0, wt_rows, _raw_stream()),
           "conv_igemm")
 
 

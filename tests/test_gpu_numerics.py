@@ -317,3 +317,79 @@ def test_validate_loop_uses_device_side_topk():
     data = [(torch.rand(8, 3, 64, 64), torch.randint(0, 16, (8,))) for _ in range(3)]
     out = validate(data, model, ops.softmax_cross_entropy, get_logger("test"), torch.device(DEV), BF)
     assert out["samples"] == 24 and 0.0 <= out["top1"] <= out["top5"] <= 1.0 and math.isfinite(out["loss"])
+
+
+# ---- tensors beyond 2 GiB -----------------------------------------------------
+@pytest.mark.parametrize("case", [(1400, 256, 56, 64, 1), (5400, 64, 56, 64, 3)], ids=["1x1_2.25GB", "3x3_2.17GB"])
+def test_conv_kernels_on_tensors_beyond_2gib(case):
+    """Input (and input gradient) of 2.2 GB: the buffer descriptors are re-based per tile / per
+    split, offsets inside stay 32-bit.  Sampled images against fp32, the weight gradient in full."""
+    hip = _hip()
+    B, Cin, H, Cout, k = case
+    pad = k // 2
+    g = torch.Generator(device=DEV).manual_seed(B)
+    x = torch.empty((B, Cin, H, H), dtype=BF, device=DEV).contiguous(memory_format=CL)
+    for i in range(0, B, 200):      # filled in slices: no 9 GB fp32 temporary
+        x[i:i + 200] = torch.randn((min(200, B - i), Cin, H, H), generator=g, device=DEV).to(BF)
+    assert x.numel() * 2 > (1 << 31)
+    x.requires_grad_(True)
+    w = (torch.randn((Cout, Cin, k, k), generator=g, device=DEV) / math.sqrt(Cin * k * k)).to(BF)
+    w = w.contiguous(memory_format=CL).requires_grad_(True)
+    y, stats = hip.conv2d_stats(x, w, 1, pad, True)
+    gy = torch.empty_like(y)
+    for i in range(0, B, 200):
+        gy[i:i + 200] = torch.randn((min(200, B - i), Cout, H, H), generator=g, device=DEV).to(BF)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    wr = w.detach().float().contiguous().requires_grad_(True)
+    sample = [0, 1, B // 2, B - 2, B - 1]          # the last images live beyond the 2 GiB mark
+    xs = x.detach()[sample].float().contiguous().requires_grad_(True)
+    ys = F.conv2d(xs, wr, None, 1, pad)
+    assert relerr(y.detach()[sample], ys) < 1.5e-2 and rms_relerr(y.detach()[sample], ys) < 4e-3
+    (dxs,) = torch.autograd.grad(ys, xs, gy[sample].float())
+    assert relerr(x.grad[sample], dxs) < 1.5e-2 and rms_relerr(x.grad[sample], dxs) < 4e-3
+    dw = torch.zeros_like(wr)
+    for i in range(0, B, 100):
+        xc = x.detach()[i:i + 100].float().contiguous()
+        dw += torch.autograd.grad(F.conv2d(xc, wr, None, 1, pad), wr, gy[i:i + 100].float())[0]
+    assert relerr(w.grad, dw) < 1.5e-2 and rms_relerr(w.grad, dw) < 4e-3, (relerr(w.grad, dw), rms_relerr(w.grad, dw))
+
+
+def test_resnet50_batch_1408_of_replicated_images_equals_batch_128():
+    """Every kernel of the training step on > 2 GiB tensors (the stem output of 1408 images is
+    2.26 GB, every layer-1 tensor 2.26 GB): a batch made of 176 copies of the same 8 images has the
+    batch statistics, the mean loss and the mean gradients of a batch of 16 copies, so any 32-bit
+    offset that wraps shows up as a difference between the two runs.  (The reference run is itself
+    replicated because a freshly initialised 50-layer net amplifies rounding differences: 8 images
+    against 2 copies of them already differ by 2 % in fp32 ATen gradients, 16 against 176 copies do
+    not - scripts/debug_big_batch.py.)"""
+    from distributeddeeplearning_amd.models import resnet50
+    from distributeddeeplearning_amd.ops import functional as ops
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x8 = torch.rand((8, 3, 224, 224), generator=g).to(DEV).to(BF).contiguous(memory_format=CL)
+    y8 = torch.randint(0, 1000, (8,), generator=g).to(DEV)
+
+    def run(rep):
+        _hip().reset_caches()
+        torch.manual_seed(0)
+        model = resnet50(num_classes=1000, zero_init_residual=True).to_compute(torch.device(DEV), BF).train()
+        opt = FusedSGD(model.named_parameters(), lr=0.0, momentum=0.0)
+        x = x8.repeat(rep, 1, 1, 1).contiguous(memory_format=CL)
+        y = y8.repeat(rep)
+        opt.zero_grad()
+        loss = ops.softmax_cross_entropy(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.float().clone() for n, p in model.named_parameters()}
+        rm = model.bn1.running_mean.detach().clone()
+        return float(loss.detach()), grads, rm
+
+    lref, gref, rmref = run(16)
+    torch.cuda.empty_cache()
+    lbig, gbig, rmbig = run(176)
+    assert abs(lbig - lref) < 1e-4 * abs(lref), (lbig, lref)
+    assert torch.allclose(rmbig, rmref, rtol=1e-3, atol=1e-5)
+    worst = max((rms_relerr(gbig[n], gref[n]), n) for n in gref if float(gref[n].abs().max()) > 0)
+    assert worst[0] < 3e-2, worst
