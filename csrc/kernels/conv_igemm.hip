@@ -35,6 +35,15 @@ struct IGemmParams {
     float* stats;          // optional [tilesM][2][N] partial sums of y and y^2 (bf16-rounded y)
     long long x_bytes;     // whole input tensor; every workgroup addresses it relative to its first image (32-bit offsets)
     unsigned w_bytes;
+    // DUAL (plain-GEMM launches only): a second reduction segment appended to the first,
+    //   y[m][n] = sum_c x[m][c] w[n][c] + sum_j x2[m][j] w2[n][j] + bias[n]
+    // (BatchNorm backward by linearity: the gradient of a 1x1 conv's input from g and z instead of dy)
+    const bf16_t* x2;
+    const bf16_t* w2;
+    const float* bias;     // optional [N] fp32, added before the bf16 rounding
+    long long x2_bytes;
+    unsigned w2_bytes;
+    int C2;
     int wt_rows;           // WT: reduction rows (forward output channels) the weight tensor really has (<= C)
     int wt;                // backward-data reads the FORWARD weights w[k][r][s][n] ("KRSC", n contiguous) through transposing LDS reads
     int Hin, Win, C;       // input image (logical, before dilation) and reduction channels
@@ -87,8 +96,9 @@ __device__ __forceinline__ int wt_swz(int row) {
 }
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
-template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS, bool WT = false>
+template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS, bool WT = false, bool DUAL = false>
 __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WAVES : 2) conv_igemm_kernel(const IGemmParams p) {
+    static_assert(!DUAL || (GLDS && !WT && !ADDEND), "the two-segment reduction exists for LDS-DMA plain GEMMs");
     static_assert(BM % 128 == 0, "statistics rows are per 128 output rows");
     static_assert(!WT || (GLDS && EPI != 1), "the transposed weight image is an LDS-DMA image; forward statistics never use it");
     constexpr bool STATS = EPI == 1 || EPI == 2 || EPI == 4;
@@ -154,6 +164,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
     if (x_left > 0x7fffffffLL) x_left = 0x7fffffffLL;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + x_first), 0, (int)x_left, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    long long x2_left = DUAL ? p.x2_bytes - (long long)m0 * p.C2 * 2 : 0;
+    x2_left = x2_left < 0 ? 0 : (x2_left > 0x7fffffffLL ? 0x7fffffffLL : x2_left);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? p.x2 + (long long)m0 * p.C2 : p.x), 0, (int)x2_left, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? p.w2 : p.w), 0, DUAL ? (int)p.w2_bytes : 0, 0x00020000);
 
     // GLDS (operand tiles by LDS-DMA, `buffer_load_dwordx4 ... lds`): a wave-instruction writes
     // 64 x 16 bytes at a wave-uniform LDS base + lane * 16, so the swizzle moves to the SOURCE side:
@@ -210,7 +224,20 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
     const int cpt = p.C / BK;          // K tiles per filter tap
     const int nr = r0 < p.R ? (p.R - r0 + tstep - 1) / tstep : 0;
     const int ns = s0 < p.S ? (p.S - s0 + tstep - 1) / tstep : 0;
-    const int KT = nr * ns * cpt;
+    const int KT1 = nr * ns * cpt;
+    const int KT = KT1 + (DUAL ? p.C2 / BK : 0);
+    unsigned a_voff2[DUAL ? A_LOADS : 1], b_off2[DUAL ? B_LOADS : 1];
+    if (DUAL) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            a_voff2[DUAL ? i : 0] = (m0 + row0 + i * RPP < m_lim) ? (unsigned)(((row0 + i * RPP) * p.C2 + ch * 8) * 2) : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int n = n0 + row0 + i * RPP;
+            b_off2[DUAL ? i : 0] = n < p.N ? (unsigned)((n * p.C2 + ch * 8) * 2) : 0x80000000u;
+        }
+    }
+    int kfetch = 0;   // DUAL: index of the K tile being fetched
     int kr = r0, ks = s0, kc = 0;      // tap / channel-block counters of the tile being fetched
 
     // Operand staging: the next tile's loads are issued before the current tile is consumed.
@@ -254,6 +281,20 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
 
     typedef __attribute__((address_space(3))) void* lds_void_ptr;
     auto fetch_lds = [&](int stage) {   // GLDS: global -> LDS without a register stop
+        if (DUAL && kfetch >= KT1) {        // second segment: plain rows of x2 / w2, C2 channels
+            const int k2 = (kfetch - KT1) * (BK * 2);
+            unsigned char* As2 = smem + stage * STAGE + wid * (64 / CPR) * (BK * 2);
+            unsigned char* Bs2 = As2 + A_BYTES;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (lds_void_ptr)(As2 + i * RPP * (BK * 2)), 16, (int)a_voff2[DUAL ? i : 0], k2, 0, 0);
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr2, (lds_void_ptr)(Bs2 + i * RPP * (BK * 2)), 16, (int)b_off2[DUAL ? i : 0], k2, 0, 0);
+            ++kfetch;
+            return;
+        }
+        if (DUAL) ++kfetch;
         if (kc == 0) retap();
         const int kco = kc * (BK * 2);
         unsigned char* As = smem + stage * STAGE + wid * (64 / CPR) * (BK * 2);
@@ -398,9 +439,16 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             bf16x4 v;
+            int m = wm * WM + j * 16 + fr, n = wn * WN + i * 16 + fq * 4;
+            if (DUAL && p.bias != nullptr) {   // uniform
+                const int ng = n0 + n < p.N ? n0 + n : 0;   // N % 8 == 0: a group of 4 is inside or outside as a whole
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ng);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = f2bf(acc[i][j][e] + bv[e]);
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = f2bf(acc[i][j][e]);
-            int m = wm * WM + j * 16 + fr, n = wn * WN + i * 16 + fq * 4;
+            }
             *reinterpret_cast<bf16x4*>(Os + m * OSTR + n * 2) = v;
         }
     __syncthreads();
@@ -600,6 +648,12 @@ int launch_cfg(const IGemmParams& p, hipStream_t stream) {
     // 3.47 -> 3.28 ms, the BK=64 tiles gain most (d4 3x3 512 @7: 78 -> 61 us = 974 TFLOP/s).
     // DDL_CONV_GLDS=0 selects the register-staged path (global -> VGPR -> ds_write_b128).
     static const int glds = getenv("DDL_CONV_GLDS") ? atoi(getenv("DDL_CONV_GLDS")) : 1;  // tuning knob
+    if (p.x2) {   // two-segment reduction: plain store or the EPI-2 epilogue, LDS-DMA only
+        dim3 grid(p.tiles_m * p.tiles_n), block(256);
+        if (p.ep_y) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 2, false, true, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, false, true, false, true>), grid, block, 0, stream, p);
+        return ddl_launch_status();
+    }
     if (p.wt) return launch_cfg2<BM, BN, BK, true, true>(p, stream);   // transposed weight image: LDS-DMA only
     return glds ? launch_cfg2<BM, BN, BK, true, false>(p, stream) : launch_cfg2<BM, BN, BK, false, false>(p, stream);
 }
@@ -626,13 +680,14 @@ extern "C" int ddl_conv_igemm_tiles_m_bwd(long long M, int Hout, int Wout, int i
 // `wt` = 1: `w` is the FORWARD filter w[k][r][s][n] of the convolution whose input gradient this
 // launch computes (C = its output channels k, N = its input channels n); the kernel reads it through
 // transposing LDS loads, so no flipped/transposed copy of the weights exists anywhere.
-extern "C" int ddl_conv_igemm_ex3(const void* x, const void* w, void* y, const void* addend, void* stats,
+extern "C" int ddl_conv_igemm_ex4(const void* x, const void* w, void* y, const void* addend, void* stats,
                                   long long x_numel, long long w_numel,
                                   int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
                                   int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
                                   int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
                                   const void* ep_y2, void* stats2, const void* ep_maskbits, int wt, int wt_rows,
-                                  hipStream_t stream) {
+                                  const void* x2, const void* w2, long long x2_numel, long long w2_numel, int C2,
+                                  const void* bias, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || C <= 0 || N <= 0 || R <= 0 || S <= 0) return DDL_EINVAL;
     if (C % 32 != 0 || N % 8 != 0) return DDL_EINVAL;
     if (idil != 1 && idil != 2 && idil != 4) return DDL_EINVAL;
@@ -679,6 +734,18 @@ extern "C" int ddl_conv_igemm_ex3(const void* x, const void* w, void* y, const v
     p.x_bytes = x_numel * 2; p.w_bytes = (unsigned)(w_numel * 2);
     p.wt = wt ? 1 : 0;
     p.wt_rows = wt ? wt_rows : C;
+    p.x2 = (const bf16_t*)x2; p.w2 = (const bf16_t*)w2; p.bias = (const float*)bias;
+    p.x2_bytes = x2_numel * 2; p.w2_bytes = (unsigned)(w2_numel * 2); p.C2 = C2;
+    if (x2) {
+        // second reduction segment: plain GEMM launches only (rows of x2 are the output rows)
+        const bool plain = R == 1 && S == 1 && ostride == 1 && pad == 0 && pad_w == 0 && idil == 1 && Hout == Hin && Wout == Win &&
+                           xs_h == (long long)Win * xs_w && xs_b == (long long)Hin * xs_h;
+        if (!plain || wt || addend || ep_mask || ep_maskbits || ep_y2 || !w2 || C2 <= 0 || C2 % 64 != 0) return DDL_EINVAL;
+        if (x2_numel < (long long)B * Hout * Wout * C2 || w2_numel < (long long)N * C2 || w2_numel * 2 >= 0x7fffffffLL) return DDL_EINVAL;
+        if (!ddl_aligned16(x2) || !ddl_aligned16(w2) || (bias && !ddl_aligned16(bias))) return DDL_EALIGN;
+        if (stats && !ep_y) return DDL_EINVAL;
+        if ((long long)257 * C2 * 2 >= 0x7fffffffLL) return DDL_EINVAL;
+    } else if (w2 || bias) return DDL_EINVAL;
     // timing-only probe (results are wrong): a descriptor with zero records drops every load through
     // it while the instruction stream, waits and barriers stay - prices one operand's traffic
     static const int probe = getenv("DDL_CONV_PROBE") ? atoi(getenv("DDL_CONV_PROBE")) : 0;
@@ -737,6 +804,18 @@ extern "C" int ddl_conv_igemm_ex3(const void* x, const void* w, void* y, const v
         return launch_cfg<256, 128, 32>(p, stream);  // (a BK=64 twin needs 96 KB of LDS: one workgroup per CU, 15-30 % slower)
     }
     return deep ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
+}
+
+extern "C" int ddl_conv_igemm_ex3(const void* x, const void* w, void* y, const void* addend, void* stats,
+                                  long long x_numel, long long w_numel,
+                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                  int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
+                                  int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
+                                  const void* ep_y2, void* stats2, const void* ep_maskbits, int wt, int wt_rows,
+                                  hipStream_t stream) {
+    return ddl_conv_igemm_ex4(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
+                              N, R, S, ostride, pad, pad_w, idil, addend_sub2, ep_y, ep_fcoef, ep_mask, ep_y2, stats2,
+                              ep_maskbits, wt, wt_rows, nullptr, nullptr, 0, 0, 0, nullptr, stream);
 }
 
 extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const void* addend, void* stats,

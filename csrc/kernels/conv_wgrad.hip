@@ -313,6 +313,60 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
+// BatchNorm backward by linearity (the BatchNorm that follows a 1x1 conv, dy = ca*g + cb*y + cc with
+// y = z W^T): the weight gradient dy^T z from the RAW product g^T z (the slabs), the Gram term
+// T = W (z^T z) and the column sums of z,
+//   out[c][j] (+)= ca[c] * sum_s partial[s][c][j] + cb[c] * T[c][j] + cc[c] * colz[j]
+// Same block shape and the same fixed summation order as splitk_reduce_kernel.
+template <typename OutT, bool ACCUM, int SL>
+__global__ void __launch_bounds__(256) splitk_reduce_lin_kernel(const float* __restrict__ partial, OutT* __restrict__ out,
+                                                               long long n, int splits, long long slab,
+                                                               const float* __restrict__ coef, int C, const bf16_t* __restrict__ T,
+                                                               const float* __restrict__ colz, int row_len) {
+    constexpr int COLS = 256 / SL;
+    __shared__ f32x4 red[SL > 1 ? 256 : 1];
+    const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+    const long long n4 = n >> 2;
+    const long long i = (long long)blockIdx.x * COLS + col;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        int k = sl;
+        for (; k + 3 * SL < splits; k += 4 * SL) {
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(partial + (long long)k * slab + (i << 2));
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(partial + (long long)(k + SL) * slab + (i << 2));
+            f32x4 v2 = *reinterpret_cast<const f32x4*>(partial + (long long)(k + 2 * SL) * slab + (i << 2));
+            f32x4 v3 = *reinterpret_cast<const f32x4*>(partial + (long long)(k + 3 * SL) * slab + (i << 2));
+            s += (v0 + v1) + (v2 + v3);
+        }
+        for (; k < splits; k += SL) s += *reinterpret_cast<const f32x4*>(partial + (long long)k * slab + (i << 2));
+    }
+    if (SL > 1) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sl != 0) return;
+        for (int l = 1; l < SL; ++l) s += red[l * COLS + col];
+    }
+    if (i >= n4) return;
+    const long long e0 = i << 2;
+    const int c = (int)(e0 / row_len), j = (int)(e0 - (long long)c * row_len);
+    const float ca = coef[c], cb = coef[C + c], cc = coef[2 * C + c];
+    const bf16x4 tv = *reinterpret_cast<const bf16x4*>(T + e0);
+    const f32x4 cz = *reinterpret_cast<const f32x4*>(colz + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = ca * s[e] + cb * bf2f(tv[e]) + cc * cz[e];
+    if constexpr (sizeof(OutT) == 4) {
+        f32x4* o = reinterpret_cast<f32x4*>(out + e0);
+        if (ACCUM) s += *o;
+        *o = s;
+    } else {
+        bf16x4* o = reinterpret_cast<bf16x4*>(out + e0);
+        if (ACCUM) { bf16x4 old = *o; for (int e = 0; e < 4; ++e) s[e] += bf2f(old[e]); }
+        bf16x4 v;
+        for (int e = 0; e < 4; ++e) v[e] = f2bf(s[e]);
+        *o = v;
+    }
+}
+
 template <int BMw, int BNw>
 int launch_wgrad(WgradParams& p, hipStream_t stream) {
     p.tiles_k = (p.K + BMw - 1) / BMw;
@@ -443,6 +497,26 @@ extern "C" int ddl_splitk_reduce(const void* partial, void* out, long long n, in
     dim3 grid((unsigned)((n4 + 256 / sl - 1) / (256 / sl))), block(256);
 #define RL3(T, A, S) hipLaunchKernelGGL((splitk_reduce_kernel<T, A, S>), grid, block, 0, stream, (const float*)partial, (T*)out, n, splits, slab)
 #define RL(T, A) do { if (sl == 16) RL3(T, A, 16); else if (sl == 4) RL3(T, A, 4); else RL3(T, A, 1); } while (0)
+    if (out_is_bf16) { if (accumulate) RL(bf16_t, true); else RL(bf16_t, false); }
+    else { if (accumulate) RL(float, true); else RL(float, false); }
+#undef RL3
+#undef RL
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_splitk_reduce_lin(const void* partial, void* out, long long n, int splits, long long slab,
+                                     int out_is_bf16, int accumulate, const void* coef, int C, const void* T,
+                                     const void* colz, int row_len, hipStream_t stream) {
+    if (!partial || !out || !coef || !T || !colz || n <= 0 || splits <= 0 || (n & 3) || slab < n || (slab & 3)) return DDL_EINVAL;
+    if (C <= 0 || row_len <= 0 || (row_len & 3) || n != (long long)C * row_len) return DDL_EINVAL;
+    if (!ddl_aligned16(partial) || (reinterpret_cast<uintptr_t>(out) & 7) || (reinterpret_cast<uintptr_t>(T) & 7) || !ddl_aligned16(colz)) return DDL_EALIGN;
+    if (!out_is_bf16 && !ddl_aligned16(out)) return DDL_EALIGN;
+    const long long n4 = n / 4;
+    const int sl = splits >= 64 ? 16 : (splits >= 8 ? 4 : 1);
+    dim3 grid((unsigned)((n4 + 256 / sl - 1) / (256 / sl))), block(256);
+#define RL3(TT, A, S) hipLaunchKernelGGL((splitk_reduce_lin_kernel<TT, A, S>), grid, block, 0, stream, (const float*)partial, (TT*)out, n, splits, slab, \
+                                        (const float*)coef, C, (const bf16_t*)T, (const float*)colz, row_len)
+#define RL(TT, A) do { if (sl == 16) RL3(TT, A, 16); else if (sl == 4) RL3(TT, A, 4); else RL3(TT, A, 1); } while (0)
     if (out_is_bf16) { if (accumulate) RL(bf16_t, true); else RL(bf16_t, false); }
     else { if (accumulate) RL(float, true); else RL(float, false); }
 #undef RL3

@@ -655,6 +655,43 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// BatchNorm backward by linearity, weight preparation.  For the BatchNorm behind a 1x1 conv
+// (y = z W^T, dy = ca*g + cb*y + cc per channel c) the input gradient is
+//   dz = g (diag(ca) W) + z (W^T diag(cb) W) + 1 (cc^T W)
+// From the transposed filter wt[k][c] = W[c][k] (row k = conv input channel, ld elements apart):
+//   b1[k][c] = wt[k][c]*ca[c]   (first-segment weights of the two-segment GEMM)
+//   a2[k][c] = wt[k][c]*cb[c]   (left factor of Q = a2 wt^T)
+//   bias[k]  = sum_c wt[k][c]*cc[c]
+// One block per row k, 8 channels per thread (C <= 2048).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_lin_prep_kernel(const bf16_t* __restrict__ wt, int ld, const float* __restrict__ coef,
+                                                         int C, bf16_t* __restrict__ b1, bf16_t* __restrict__ a2,
+                                                         float* __restrict__ bias) {
+    __shared__ float red[4];
+    const int k = blockIdx.x, c = threadIdx.x * 8;
+    float acc = 0.f;
+    if (c < C) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wt + (long long)k * ld + c);
+        float ca[8], cb[8], cc[8];
+        load8f(coef + c, ca); load8f(coef + C + c, cb); load8f(coef + 2 * C + c, cc);
+        bf16x8 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = bf2f(w[e]);
+            o1[e] = f2bf(f * ca[e]); o2[e] = f2bf(f * cb[e]);
+            acc += f * cc[e];
+        }
+        *reinterpret_cast<bf16x8*>(b1 + (long long)k * C + c) = o1;
+        *reinterpret_cast<bf16x8*>(a2 + (long long)k * C + c) = o2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bias[k] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weight flip-transpose for backward-data, all tensors in one launch:
 //   dst[c][R-1-r][S-1-s][k] = src[k][r][s][c]   (k padded with zeros up to Kpad)
 // One block moves a 64(k) x 64(c) tile of one tap through LDS with 16-byte global accesses on
@@ -1028,3 +1065,20 @@ extern "C" int ddl_label_rank(const void* logits, const void* labels, void* rank
     return ddl_launch_status();
 }
 
+
+extern "C" int ddl_bn_lin_prep(const void* wt, int ld, const void* coef, int C, int rows, void* b1, void* a2, void* bias,
+                               hipStream_t stream) {
+    CHK(wt && coef && b1 && a2 && bias && C > 0 && C <= 2048 && (C & 7) == 0 && rows > 0 && ld >= C && (ld & 7) == 0, DDL_EINVAL);
+    CHK(ddl_aligned16(wt) && ddl_aligned16(coef) && ddl_aligned16(b1) && ddl_aligned16(a2), DDL_EALIGN);
+    hipLaunchKernelGGL(bn_lin_prep_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)wt, ld, (const float*)coef, C,
+                       (bf16_t*)b1, (bf16_t*)a2, (float*)bias);
+    return ddl_launch_status();
+}
+
+// out[2][C] = sum over the T rows of partial[T][2][C] (one slice of the fold kernel)
+extern "C" int ddl_bn_colsum_fold(const void* partial, int T, int C, void* out, hipStream_t stream) {
+    CHK(partial && out && T > 0 && C > 0, DDL_EINVAL);
+    hipLaunchKernelGGL((bn_stats_fold_kernel<float>), dim3((C + 15) / 16, 1), dim3(256), 0, stream, (const float*)partial, T, C, 1,
+                       (float*)out);
+    return ddl_launch_status();
+}

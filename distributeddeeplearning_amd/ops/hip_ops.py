@@ -660,6 +660,129 @@ def _unit_bwd(dz, y, z, gamma, beta, coeffs, mask, want_g, partial=None):
     return dy, dg, db, g
 
 
+# ---- BatchNorm backward of a bottleneck's last unit by linearity -----------------------------------
+# dy3 = ca*g + cb*y3 + cc per channel and y3 = z2 W3^T (1x1 conv), hence
+#   dz2 = g (diag(ca) W3) + z2 (W3^T diag(cb) W3) + 1 (cc^T W3)                    (input gradient)
+#   dW3 = diag(ca) (g^T z2) + diag(cb) W3 (z2^T z2) + cc (x) colsum(z2)             (weight gradient)
+# so dy3 - three passes over the block's WIDEST tensor (read g, read y3, write dy3, then read twice
+# more by the two GEMMs) - never exists.  The input gradient becomes ONE two-segment GEMM over g and
+# z2 (K grows by a quarter); the weight gradient is the raw product g^T z2 plus a Gram matrix of the
+# narrow activation, fixed up in the split-K reduction.  Costed in profiles/r1_notes.md (the apply
+# pass alone: 1.57 ms of the 19.2 ms step); numerics in benchmarks/bn_linearity_check.py and the
+# block / trajectory tests.  DDL_BN3_LINEAR=0 restores the materialised dy3.
+_BN3_LINEAR = {"on": _os.environ.get("DDL_BN3_LINEAR", "1") != "0"}
+
+
+def _unit_coef(dz, y, gamma, beta, coeffs, partial):
+    """Finalize pass only of a BatchNorm backward whose reduce partials already exist: returns the
+    scratch tensor whose first 3*C floats are (ca, cb, cc); dgamma/dbeta go where _unit_bwd puts
+    them (returned as (tmp, dg, db))."""
+    B, C, H, W = y.shape
+    M = B * H * W
+    dev = y.device
+    cb = coeffs.data_ptr()
+    G = partial.shape[0]
+    P = K._fold_slices(G) if G > 512 else 0
+    tmp = torch.empty(3 * C + 2 * P * C, dtype=torch.float32, device=dev)
+    coef = tmp.data_ptr()
+    wk = coef + 12 * C if P else None
+    direct = _DIRECT["on"] and _direct_grad_ok(gamma) and _direct_grad_ok(beta) and \
+        gamma.grad.dtype == torch.float32 and beta.grad.dtype == torch.float32
+    if direct:
+        K.bn_bwd_finalize(partial.data_ptr(), G, C, M, gamma, cb, cb + 4 * C, gamma.grad, beta.grad, coef,
+                          accumulate=True, work=wk)
+        dg = db = None
+        _notify(gamma)
+        _notify(beta)
+    else:
+        dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+        K.bn_bwd_finalize(partial.data_ptr(), G, C, M, gamma, cb, cb + 4 * C, dgb[0], dgb[1], coef, work=wk)
+        dg, db = dgb[0], dgb[1]
+    return tmp, dg, db
+
+
+def _bn3_linear_ok(w, stride, padding, g, z2):
+    Kc, C2, R, S = w.shape
+    return _BN3_LINEAR["on"] and not _WT_KRSC and R == 1 and S == 1 and stride == 1 and padding == 0 and \
+        C2 % 64 == 0 and Kc % 32 == 0 and Kc <= 2048 and g.shape[1] == Kc and z2.shape[1] == C2 and \
+        g.shape[2:] == z2.shape[2:]
+
+
+def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
+    """Input gradient of the 1x1 conv behind the BatchNorm whose backward coefficients are in
+    ``coef_t``: g [B, C, H, W] is that BatchNorm's (ReLU-masked) output gradient, z2 the conv's
+    input.  Returns (g2, partial) like _conv_dgrad_bn: the ReLU-masked gradient of the previous
+    unit's BatchNorm output and its backward partial sums."""
+    B, C, H, W = g.shape
+    C2 = z2.shape[1]
+    dev = g.device
+    wt3 = _WT.get(w)                      # [C2][C]: wt3[k][c] = w[c][k]
+    scratch = torch.empty(2 * C2 * C + C2 * C2, dtype=_BF16, device=dev)
+    b1, a2, q = scratch[:C2 * C], scratch[C2 * C: 2 * C2 * C], scratch[2 * C2 * C:]
+    bias = torch.empty(C2, dtype=torch.float32, device=dev)
+    K.bn_lin_prep(wt3, C, coef_t.data_ptr(), C, C2, b1, a2, bias)
+    # Q[k][j] = sum_c cb[c] w[c][k] w[c][j]: a2 (rows k) times wt3^T, a C2 x C2 GEMM over C
+    K.conv_igemm(a2, (C2, 1, 1, C, C, C, C, a2.numel()), wt3, q, C2, 1, 1, 1, 0, 0, 1, 1, 1)
+    T = K.conv_tiles_m_bwd(B * H * W, H, W, 1, 1)
+    partial = torch.empty((T, 2, C2), dtype=torch.float32, device=dev)
+    g2 = _empty_nhwc(B, C2, H, W, dev)
+    K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, stats=partial, ep_y=y_prev,
+                 ep_fcoef=fcoef_prev, x2=z2, w2=q, c2=C2, bias=bias)
+    return g2, partial
+
+
+def _bn3_linear_wgrad(g, z2, w, coef_t):
+    """dW3 by linearity, into ``w.grad`` when that is a live arena view (returns None and notifies),
+    else returned.  Runs on the weight-gradient stream like _conv_wgrad."""
+    C, C2 = w.shape[0], w.shape[1]
+    direct = _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]
+    out = w.grad if direct else torch.zeros_like(w)
+    side = _side_stream(g.device) if (_SIDE["on"] and direct) else None
+
+    def body():
+        dev = g.device
+        B, _, H, W = g.shape
+        M = B * H * W
+        gz = _geom(z2)
+        # raw product g^T z2 (split-K slabs, reduced below with the correction terms)
+        splits = K.conv_wgrad_splits(M, C, C2, 1, 1)
+        slab = C * C2
+        partial = torch.empty((splits, slab), dtype=torch.float32, device=dev)
+        K.conv_wgrad(g, z2, gz, partial, C, 1, 1, 1, 0, 0, H, W, splits)
+        # Gram matrix of the narrow activation and its column sums
+        s2 = K.conv_wgrad_splits(M, C2, C2, 1, 1)
+        gp = torch.empty((s2, C2 * C2), dtype=torch.float32, device=dev)
+        K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2)
+        gram = torch.empty(C2 * C2, dtype=_BF16, device=dev)
+        K.splitk_reduce(gp, gram, C2 * C2, s2, C2 * C2, False)
+        rows = 512
+        Tz = (M + rows - 1) // rows
+        zp = torch.empty((Tz + 1, 2, C2), dtype=torch.float32, device=dev)
+        K.bn_stats_partial(z2, zp, M, C2, rows)
+        K.bn_colsum_fold(zp, Tz, C2, zp[Tz])
+        # T = W3 (z2^T z2): rows c of the filter times the (symmetric) Gram matrix
+        t = torch.empty(C * C2, dtype=_BF16, device=dev)
+        K.conv_igemm(w, (C, 1, 1, C2, C2, C2, C2, w.numel()), gram, t, C2, 1, 1, 1, 0, 0, 1, 1, 1)
+        K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, zp[Tz], C2)
+
+    if side is None:
+        body()
+    else:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()
+        _side_mark_used()
+        if _SIDE["join_queued"]:
+            _SIDE["keep"].append((g, z2, coef_t))
+        else:
+            for t_ in (g, z2, coef_t):
+                t_.record_stream(side)
+    if direct:
+        _notify(w)
+        return None
+    return out
+
+
 class ConvFn(Function):
     """y = conv2d(x, w) (no bias); optionally also the per-tile BatchNorm partial sums."""
 
@@ -1023,10 +1146,21 @@ class ResidualBlockFn(Function):
                 mask = 0            # dz already carries the ReLU mask
             else:
                 mask = 1 if last else 2
+            inp = zs[i - 1] if i > 0 else x
+            if last and i > 0 and mask == 0 and fused is not None and _FUSE_BN_REDUCE["on"] and \
+                    _bn3_linear_ok(w, strides[i], pads[i], dz, inp):
+                # the wide unit by linearity: its dy never exists (see _bn3_linear_dgrad)
+                coef_t, dg, db = _unit_coef(dz, ys[i], gam, bet, cs[i], fused)
+                g_short = dz
+                dw = _bn3_linear_wgrad(dz, inp, w, coef_t)
+                put(i, dw, dg, db)
+                dz, fused = _bn3_linear_dgrad(dz, inp, w, coef_t, ys[i - 1],
+                                              cs[i - 1].data_ptr() + 8 * inp.shape[1])
+                _flush_notifications()
+                continue
             dy, dg, db, g = _unit_bwd(dz, ys[i], zs[i], gam, bet, cs[i], mask, last, partial=fused)
             if last:
                 g_short = g
-            inp = zs[i - 1] if i > 0 else x
             dw = _conv_wgrad(dy, inp, w, strides[i], pads[i])
             put(i, dw, dg, db)
             if i > 0:

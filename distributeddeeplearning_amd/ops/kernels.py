@@ -225,11 +225,13 @@ def storage_numel_from(x):
 
 def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil, Hout, Wout,
                addend=None, stats=None, addend_sub2=False, ep_y=None, ep_fcoef=None, ep_mask=None,
-               ep_y2=None, stats2=None, ep_maskbits=None, wt_rows=0):
+               ep_y2=None, stats2=None, ep_maskbits=None, wt_rows=0, x2=None, w2=None, c2=0, bias=None):
     """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel).
 
     ``wt_rows`` > 0: backward-data mode - ``w`` is the FORWARD filter ``[wt_rows][R][S][n_out]`` and
     the kernel transposes it on the way from LDS to the matrix cores (no transposed copy exists).
+    ``x2`` [M, c2] / ``w2`` [n_out, c2] / ``bias`` [n_out] fp32 (plain-GEMM launches only): a second
+    reduction segment and a per-channel constant, ``y = x w^T + x2 w2^T + bias``.
 
     Fused backward epilogues: ``ep_y`` + ``ep_fcoef`` (+ ``stats``) store the gradient masked by
     the ReLU of ``bn(ep_y)`` and emit the BatchNorm-backward partial sums per tile; ``ep_mask``
@@ -252,11 +254,12 @@ def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil,
         raise KernelError("conv_igemm: second partial buffer missing or too small")
     if ep_maskbits is not None and (ep_mask is not None or ep_maskbits.numel() * 8 < y.numel()):
         raise KernelError("conv_igemm: ep_maskbits excludes ep_mask and must cover the output")
-    f = _fn("ddl_conv_igemm_ex3", "ppppp qq iiii qqq iiiiiiiiii pppppp ii p")
+    f = _fn("ddl_conv_igemm_ex4", "ppppp qq iiii qqq iiiiiiiiii pppppp ii pp qq i p p")
     check(f(x_ptr_tensor.data_ptr(), _p(w), y.data_ptr(), _p(addend), _p(stats), xn,
             w.numel(), B, Hin, Win, C, sb, sh, sw, Hout, Wout, n_out, R, S, ostride, pad, pad_w, idil,
             1 if addend_sub2 else 0, _p(ep_y), _p(ep_fcoef), _p(ep_mask), _p(ep_y2), _p(stats2),
-            _p(ep_maskbits), 1 if wt_rows else 0, wt_rows, _raw_stream()),
+            _p(ep_maskbits), 1 if wt_rows else 0, wt_rows, _p(x2), _p(w2),
+            0 if x2 is None else x2.numel(), 0 if w2 is None else w2.numel(), c2, _p(bias), _raw_stream()),
           "conv_igemm")
 
 
@@ -291,6 +294,24 @@ def splitk_reduce(partial, out, n, splits, slab, accumulate=False, stream=None):
     check(f(_p(partial), out.data_ptr(), n, splits, slab,
             1 if out.dtype == torch.bfloat16 else 0, 1 if accumulate else 0,
             _raw_stream() if stream is None else stream), "splitk_reduce")
+
+
+def splitk_reduce_lin(partial, out, n, splits, slab, accumulate, coef, C, T, colz, row_len):
+    """out (+)= ca[c]*sum_s partial[s] + cb[c]*T + cc[c]*colz[j] (BatchNorm backward by linearity)."""
+    f = _fn("ddl_splitk_reduce_lin", "pp qiq ii p i pp i p")
+    check(f(_p(partial), out.data_ptr(), n, splits, slab, 1 if out.dtype == torch.bfloat16 else 0,
+            1 if accumulate else 0, _p(coef), C, _p(T), _p(colz), row_len, _raw_stream()), "splitk_reduce_lin")
+
+
+def bn_lin_prep(wt, ld, coef, C, rows, b1, a2, bias):
+    f = _fn("ddl_bn_lin_prep", "pi pii ppp p")
+    check(f(_p(wt), ld, _p(coef), C, rows, _p(b1), _p(a2), _p(bias), _raw_stream()), "bn_lin_prep")
+
+
+def bn_colsum_fold(partial, T, C, out):
+    """out[2][C] = column sums of a [T][2][C] partial table (fixed order)."""
+    f = _fn("ddl_bn_colsum_fold", "p ii p p")
+    check(f(_p(partial), T, C, _p(out), _raw_stream()), "bn_colsum_fold")
 
 
 # ---- batch norm / pooling / loss (csrc/kernels/nn_kernels.hip) -------------------------------
