@@ -733,44 +733,44 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
 
 def _bn3_linear_wgrad(g, z2, w, coef_t):
     """dW3 by linearity, into ``w.grad`` when that is a live arena view (returns None and notifies),
-    else returned.  Runs on the weight-gradient stream like _conv_wgrad."""
+    else returned.  Runs on the weight-gradient stream like _conv_wgrad: raw stream handle, one
+    persistent workspace carved by address (no torch stream switch, no allocations)."""
     C, C2 = w.shape[0], w.shape[1]
     direct = _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]
     out = w.grad if direct else torch.zeros_like(w)
     side = _side_stream(g.device) if (_SIDE["on"] and direct) else None
-
-    def body():
-        dev = g.device
-        B, _, H, W = g.shape
-        M = B * H * W
-        gz = _geom(z2)
-        # raw product g^T z2 (split-K slabs, reduced below with the correction terms)
-        splits = K.conv_wgrad_splits(M, C, C2, 1, 1)
-        slab = C * C2
-        partial = torch.empty((splits, slab), dtype=torch.float32, device=dev)
-        K.conv_wgrad(g, z2, gz, partial, C, 1, 1, 1, 0, 0, H, W, splits)
-        # Gram matrix of the narrow activation and its column sums
-        s2 = K.conv_wgrad_splits(M, C2, C2, 1, 1)
-        gp = torch.empty((s2, C2 * C2), dtype=torch.float32, device=dev)
-        K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2)
-        gram = torch.empty(C2 * C2, dtype=_BF16, device=dev)
-        K.splitk_reduce(gp, gram, C2 * C2, s2, C2 * C2, False)
-        rows = 512
-        Tz = (M + rows - 1) // rows
-        zp = torch.empty((Tz + 1, 2, C2), dtype=torch.float32, device=dev)
-        K.bn_stats_partial(z2, zp, M, C2, rows)
-        K.bn_colsum_fold(zp, Tz, C2, zp[Tz])
-        # T = W3 (z2^T z2): rows c of the filter times the (symmetric) Gram matrix
-        t = torch.empty(C * C2, dtype=_BF16, device=dev)
-        K.conv_igemm(w, (C, 1, 1, C2, C2, C2, C2, w.numel()), gram, t, C2, 1, 1, 1, 0, 0, 1, 1, 1)
-        K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, zp[Tz], C2)
-
+    B, _, H, W = g.shape
+    M = B * H * W
+    gz = _geom(z2)
+    splits = K.conv_wgrad_splits(M, C, C2, 1, 1)      # raw product g^T z2
+    s2 = K.conv_wgrad_splits(M, C2, C2, 1, 1)         # Gram matrix z2^T z2
+    slab, gslab = C * C2, C2 * C2
+    rows = 512
+    Tz = (M + rows - 1) // rows
+    sizes = (4 * splits * slab, 4 * s2 * gslab, 2 * gslab, 4 * (Tz + 1) * 2 * C2, 2 * slab)
+    offs, total = [], 0
+    for nb in sizes:
+        offs.append(total)
+        total += (nb + 255) // 256 * 256
     if side is None:
-        body()
+        ws_t = torch.empty(total, dtype=torch.uint8, device=g.device)
+        base, raw = ws_t.data_ptr(), None
     else:
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            body()
+        raw = side.cuda_stream
+        K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
+        base = _side_workspace(total)
+    partial, gp, gram, zp, t = (base + o for o in offs)
+    colz = zp + 4 * Tz * 2 * C2
+    K.conv_wgrad(g, z2, gz, partial, C, 1, 1, 1, 0, 0, H, W, splits, stream=raw)
+    K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2, stream=raw)
+    K.splitk_reduce(gp, gram, gslab, s2, gslab, False, stream=raw, out_bf16=True)
+    K.bn_stats_partial(z2, zp, M, C2, rows, stream=raw)
+    K.bn_colsum_fold(zp, Tz, C2, colz, stream=raw)
+    # T = W3 (z2^T z2): rows c of the filter times the (symmetric) Gram matrix
+    K.conv_igemm(w, (C, 1, 1, C2, C2, C2, C2, w.numel()), gram, _RawOut(t, slab), C2, 1, 1, 1, 0, 0, 1, 1, 1,
+                 stream=raw, w_numel=gslab)
+    K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, colz, C2, stream=raw)
+    if side is not None:
         _side_mark_used()
         if _SIDE["join_queued"]:
             _SIDE["keep"].append((g, z2, coef_t))
@@ -781,6 +781,22 @@ def _bn3_linear_wgrad(g, z2, w, coef_t):
         _notify(w)
         return None
     return out
+
+
+class _RawOut:
+    """Output operand given by raw address (a slice of a workspace) for launchers that ask the
+    tensor for ``data_ptr()`` / ``numel()``."""
+
+    __slots__ = ("ptr", "n")
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numel(self):
+        return self.n
 
 
 class ConvFn(Function):
@@ -1152,10 +1168,12 @@ class ResidualBlockFn(Function):
                 # the wide unit by linearity: its dy never exists (see _bn3_linear_dgrad)
                 coef_t, dg, db = _unit_coef(dz, ys[i], gam, bet, cs[i], fused)
                 g_short = dz
-                dw = _bn3_linear_wgrad(dz, inp, w, coef_t)
-                put(i, dw, dg, db)
-                dz, fused = _bn3_linear_dgrad(dz, inp, w, coef_t, ys[i - 1],
+                # the dependent chain first (the host is what the main stream waits for in the late
+                # layers: issuing the side-stream work first left 40-140 us holes in front of the prep kernel)
+                dz, fused = _bn3_linear_dgrad(g_short, inp, w, coef_t, ys[i - 1],
                                               cs[i - 1].data_ptr() + 8 * inp.shape[1])
+                dw = _bn3_linear_wgrad(g_short, inp, w, coef_t)
+                put(i, dw, dg, db)
                 _flush_notifications()
                 continue
             dy, dg, db, g = _unit_bwd(dz, ys[i], zs[i], gam, bet, cs[i], mask, last, partial=fused)

@@ -225,7 +225,7 @@ def storage_numel_from(x):
 
 def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil, Hout, Wout,
                addend=None, stats=None, addend_sub2=False, ep_y=None, ep_fcoef=None, ep_mask=None,
-               ep_y2=None, stats2=None, ep_maskbits=None, wt_rows=0, x2=None, w2=None, c2=0, bias=None):
+               ep_y2=None, stats2=None, ep_maskbits=None, wt_rows=0, x2=None, w2=None, c2=0, bias=None, stream=None, w_numel=None):
     """Raw launcher.  ``geom`` = (B, Hin, Win, C, xs_b, xs_h, xs_w, x_numel).
 
     ``wt_rows`` > 0: backward-data mode - ``w`` is the FORWARD filter ``[wt_rows][R][S][n_out]`` and
@@ -256,10 +256,11 @@ def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil,
         raise KernelError("conv_igemm: ep_maskbits excludes ep_mask and must cover the output")
     f = _fn("ddl_conv_igemm_ex4", "ppppp qq iiii qqq iiiiiiiiii pppppp ii pp qq i p p")
     check(f(x_ptr_tensor.data_ptr(), _p(w), y.data_ptr(), _p(addend), _p(stats), xn,
-            w.numel(), B, Hin, Win, C, sb, sh, sw, Hout, Wout, n_out, R, S, ostride, pad, pad_w, idil,
+            w.numel() if w_numel is None else w_numel, B, Hin, Win, C, sb, sh, sw, Hout, Wout, n_out, R, S, ostride, pad, pad_w, idil,
             1 if addend_sub2 else 0, _p(ep_y), _p(ep_fcoef), _p(ep_mask), _p(ep_y2), _p(stats2),
             _p(ep_maskbits), 1 if wt_rows else 0, wt_rows, _p(x2), _p(w2),
-            0 if x2 is None else x2.numel(), 0 if w2 is None else w2.numel(), c2, _p(bias), _raw_stream()),
+            0 if x2 is None else x2.numel(), 0 if w2 is None else w2.numel(), c2, _p(bias),
+            _raw_stream() if stream is None else stream),
           "conv_igemm")
 
 
@@ -289,18 +290,22 @@ def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hou
             _raw_stream() if stream is None else stream), "conv_wgrad")
 
 
-def splitk_reduce(partial, out, n, splits, slab, accumulate=False, stream=None):
+def splitk_reduce(partial, out, n, splits, slab, accumulate=False, stream=None, out_bf16=None):
+    """``out``: tensor, or a raw address with ``out_bf16`` saying what it holds."""
     f = _fn("ddl_splitk_reduce", "pp qiq ii p")
-    check(f(_p(partial), out.data_ptr(), n, splits, slab,
-            1 if out.dtype == torch.bfloat16 else 0, 1 if accumulate else 0,
+    if out_bf16 is None:
+        out_bf16 = out.dtype == torch.bfloat16
+    check(f(_p(partial), _p(out), n, splits, slab,
+            1 if out_bf16 else 0, 1 if accumulate else 0,
             _raw_stream() if stream is None else stream), "splitk_reduce")
 
 
-def splitk_reduce_lin(partial, out, n, splits, slab, accumulate, coef, C, T, colz, row_len):
+def splitk_reduce_lin(partial, out, n, splits, slab, accumulate, coef, C, T, colz, row_len, stream=None):
     """out (+)= ca[c]*sum_s partial[s] + cb[c]*T + cc[c]*colz[j] (BatchNorm backward by linearity)."""
     f = _fn("ddl_splitk_reduce_lin", "pp qiq ii p i pp i p")
     check(f(_p(partial), out.data_ptr(), n, splits, slab, 1 if out.dtype == torch.bfloat16 else 0,
-            1 if accumulate else 0, _p(coef), C, _p(T), _p(colz), row_len, _raw_stream()), "splitk_reduce_lin")
+            1 if accumulate else 0, _p(coef), C, _p(T), _p(colz), row_len,
+            _raw_stream() if stream is None else stream), "splitk_reduce_lin")
 
 
 def bn_lin_prep(wt, ld, coef, C, rows, b1, a2, bias):
@@ -308,16 +313,18 @@ def bn_lin_prep(wt, ld, coef, C, rows, b1, a2, bias):
     check(f(_p(wt), ld, _p(coef), C, rows, _p(b1), _p(a2), _p(bias), _raw_stream()), "bn_lin_prep")
 
 
-def bn_colsum_fold(partial, T, C, out):
+def bn_colsum_fold(partial, T, C, out, stream=None):
     """out[2][C] = column sums of a [T][2][C] partial table (fixed order)."""
     f = _fn("ddl_bn_colsum_fold", "p ii p p")
-    check(f(_p(partial), T, C, _p(out), _raw_stream()), "bn_colsum_fold")
+    check(f(_p(partial), T, C, _p(out), _raw_stream() if stream is None else stream), "bn_colsum_fold")
 
 
 # ---- batch norm / pooling / loss (csrc/kernels/nn_kernels.hip) -------------------------------
-def bn_stats_partial(y2d, partial, M, C, rows_per_tile):
-    check(lib().ddl_bn_stats_partial(ptr(y2d), ptr(partial), _i64(M), _i32(C), _i32(rows_per_tile),
-                                     stream()), "bn_stats_partial")
+def bn_stats_partial(y2d, partial, M, C, rows_per_tile, stream=None):
+    """``partial``: tensor or raw address; ``stream``: raw HIP stream (default: current)."""
+    f = _fn("ddl_bn_stats_partial", "pp qii p")
+    check(f(y2d.data_ptr(), _p(partial), M, C, rows_per_tile, _raw_stream() if stream is None else stream),
+          "bn_stats_partial")
 
 
 @functools.lru_cache(maxsize=None)
