@@ -199,6 +199,97 @@ __global__ void __launch_bounds__(1024) bn_fwd_finalize_direct_kernel(const floa
     }
 }
 
+// Long partial tables in ONE launch: grid (C/16, P) folds like bn_stats_fold_kernel, then the block
+// that finishes LAST for its 16 channels (a ticket per channel group; release by every block, acquire
+// by the last) folds the P slices in a fixed order and runs the finish - the separate finalize
+// launch and its kernel boundary (25 + 25 per ResNet-50 step, all on the dependent chain conv ->
+// statistics -> apply) are gone.  MEASURED SLOWER (19.05-19.11 ms against 18.79 ms per ResNet-50 step,
+// profiles/r2_notes.md: the agent-scope release of every block writes its XCD's L2 back while the
+// weight-gradient stream keeps it dirty), so it is opt-in: DDL_BN_ONE_LAUNCH=1.  The tickets live in a process-lifetime buffer and are reset by
+// the block that consumed them; launches that share it must be stream-ordered (they are: main stream).
+// MODE 0: forward (mean / invstd / scale / shift, running statistics); MODE 1: backward
+// (dgamma / dbeta, coefficients of dy = ca*g + cb*y + cc).
+struct BnFinishArgs {
+    long long M;
+    const float* gamma; const float* beta;
+    float* rmean; float* rvar; float momentum, eps;
+    float* mean_out; float* invstd_out; float* scale; float* shift;      // forward outputs
+    const float* mean; const float* invstd; float* dgamma; float* dbeta; float* coef; int accumulate;  // backward
+};
+
+template <typename Acc, int MODE>
+__global__ void __launch_bounds__(256) bn_fold_finish_kernel(const float* __restrict__ partial, int T, int C, int P,
+                                                            Acc* __restrict__ folded /*[P][2][C]*/, int* __restrict__ tickets,
+                                                            const BnFinishArgs a) {
+    __shared__ double r1[16][16], r2[16][16];
+    __shared__ int is_last;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
+    const int per = (T + P - 1) / P;
+    const int t0 = blockIdx.y * per;
+    int t1 = t0 + per;
+    if (t1 > T) t1 = T;
+    Acc s1 = 0, s2 = 0;
+    if (c < C) bn_fold_lane16<Acc>(partial, t0, t1, C, c, ty, s1, s2);
+    r1[ty][tx] = (double)s1; r2[ty][tx] = (double)s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double d1 = r1[0][tx], d2 = r2[0][tx];
+        for (int l = 1; l < 16; ++l) { d1 += r1[l][tx]; d2 += r2[l][tx]; }
+        folded[((long long)blockIdx.y * 2) * C + c] = (Acc)d1;
+        folded[((long long)blockIdx.y * 2 + 1) * C + c] = (Acc)d2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == P - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;     // ready for the next launch (stream-ordered)
+    double u1 = 0.0, u2 = 0.0;
+    if (c < C) {
+        for (int p = ty; p < P; p += 16) {
+            u1 += (double)folded[((long long)p * 2) * C + c];
+            u2 += (double)folded[((long long)p * 2 + 1) * C + c];
+        }
+    }
+    r1[ty][tx] = u1; r2[ty][tx] = u2;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    for (int l = 1; l < 16; ++l) { u1 += r1[l][tx]; u2 += r2[l][tx]; }
+    if (MODE == 0) {
+        bn_fwd_finish(c, u1, u2, a.M, a.gamma, a.beta, a.rmean, a.rvar, a.momentum, a.eps, a.mean_out, a.invstd_out, a.scale, a.shift);
+    } else {
+        const float f1 = (float)u1, f2 = (float)u2;
+        const float mu = a.mean[c], inv = a.invstd[c];
+        const float dg = inv * (f2 - mu * f1);
+        if (a.accumulate) { a.dgamma[c] += dg; a.dbeta[c] += f1; } else { a.dgamma[c] = dg; a.dbeta[c] = f1; }
+        const float invM = 1.f / (float)a.M;
+        const float ca = a.gamma[c] * inv;
+        const float cb = -ca * inv * dg * invM;
+        a.coef[c] = ca; a.coef[C + c] = cb; a.coef[2 * C + c] = -ca * f1 * invM - cb * mu;
+    }
+}
+
+static int* bn_tickets() {
+    // per device: 2 x 256 tickets (forward half, backward half), zeroed once, self-resetting
+    static int* bufs[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!bufs[dev]) {
+        int* b = nullptr;
+        if (hipMalloc(&b, 512 * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(b, 0, 512 * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+        bufs[dev] = b;
+    }
+    return bufs[dev];
+}
+
 // eval mode: scale/shift straight from the running statistics
 __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ rmean, const float* __restrict__ rvar,
@@ -830,6 +921,17 @@ extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long 
         return ddl_launch_status();
     }
     const int P = (int)ddl_bn_fold_slices(T);
+    static const int one = getenv("DDL_BN_ONE_LAUNCH") ? atoi(getenv("DDL_BN_ONE_LAUNCH")) : 0;   // A/B knob: measured slower, profiles/r2_notes.md
+    int* tickets = one && C <= 4096 ? bn_tickets() : nullptr;
+    if (tickets) {
+        BnFinishArgs a = {};
+        a.M = M; a.gamma = (const float*)gamma; a.beta = (const float*)beta; a.rmean = (float*)rmean; a.rvar = (float*)rvar;
+        a.momentum = momentum; a.eps = eps; a.mean_out = (float*)mean; a.invstd_out = (float*)invstd;
+        a.scale = (float*)scale; a.shift = (float*)shift;
+        hipLaunchKernelGGL((bn_fold_finish_kernel<double, 0>), dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial,
+                           T, C, P, (double*)workspace, tickets, a);
+        return ddl_launch_status();
+    }
     hipLaunchKernelGGL(bn_stats_fold_kernel<double>, dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
                        (double*)workspace);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)workspace, P, C, M,
@@ -908,6 +1010,16 @@ extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long 
     CHK(partial && gamma && mean && invstd && dgamma && dbeta && coef && G > 0 && C > 0 && M > 0, DDL_EINVAL);
     if (workspace && G > 512) {
         const int P = (int)ddl_bn_fold_slices(G);
+        static const int one = getenv("DDL_BN_ONE_LAUNCH") ? atoi(getenv("DDL_BN_ONE_LAUNCH")) : 0;   // A/B knob: measured slower, profiles/r2_notes.md
+        int* tickets = one && C <= 4096 ? bn_tickets() : nullptr;
+        if (tickets) {
+            BnFinishArgs a = {};
+            a.M = M; a.gamma = (const float*)gamma; a.mean = (const float*)mean; a.invstd = (const float*)invstd;
+            a.dgamma = (float*)dgamma; a.dbeta = (float*)dbeta; a.coef = (float*)coef; a.accumulate = accumulate;
+            hipLaunchKernelGGL((bn_fold_finish_kernel<float, 1>), dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial,
+                               G, C, P, (float*)workspace, tickets + 256, a);
+            return ddl_launch_status();
+        }
         hipLaunchKernelGGL(bn_stats_fold_kernel<float>, dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial, G, C,
                            P, (float*)workspace);
         if (ddl_launch_status() != DDL_OK) return DDL_ELAUNCH;
