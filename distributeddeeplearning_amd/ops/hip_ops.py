@@ -350,7 +350,18 @@ def _conv_dgrad_1x1s2_compact(dy, w):
     return out
 
 
-def _conv_wgrad(dy, x, w, stride, padding):
+def _side_prewait(device):
+    """Order the weight-gradient stream behind what is queued on the current stream NOW and return
+    True, so that the weight-gradient kernels themselves can be issued later (after the next kernel
+    of the dependent chain) without waiting for that kernel too.  False: no lean side stream."""
+    if not (_SIDE["on"] and _SIDE_LEAN and _DIRECT["on"] and _grad_listeners is not None):
+        return False
+    side = _side_stream(device)
+    K.stream_wait_stream(side.cuda_stream, K._raw_stream(), _SIDE["event"])
+    return True
+
+
+def _conv_wgrad(dy, x, w, stride, padding, prewaited=False):
     """dw for ``w``: written into ``w.grad`` when that is a live arena view (returns None and
     notifies the listeners), otherwise returned as a new tensor.
 
@@ -371,7 +382,8 @@ def _conv_wgrad(dy, x, w, stride, padding):
             # serves them all) - ~25 us of host time per weight gradient less
             if _SIDE_LEAN:
                 raw = side.cuda_stream
-                K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
+                if not prewaited:
+                    K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
                 _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
                             accumulate=True, stream=raw, workspace=_side_workspace)
             else:  # torch's own stream switch and events (DDL_SIDE_LEAN=0)
@@ -731,7 +743,7 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
     return g2, partial
 
 
-def _bn3_linear_wgrad(g, z2, w, coef_t):
+def _bn3_linear_wgrad(g, z2, w, coef_t, prewaited=False):
     """dW3 by linearity, into ``w.grad`` when that is a live arena view (returns None and notifies),
     else returned.  Runs on the weight-gradient stream like _conv_wgrad: raw stream handle, one
     persistent workspace carved by address (no torch stream switch, no allocations)."""
@@ -757,7 +769,8 @@ def _bn3_linear_wgrad(g, z2, w, coef_t):
         base, raw = ws_t.data_ptr(), None
     else:
         raw = side.cuda_stream
-        K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
+        if not prewaited:
+            K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
         base = _side_workspace(total)
     partial, gp, gram, zp, t = (base + o for o in offs)
     colz = zp + 4 * Tz * 2 * C2
@@ -1170,25 +1183,33 @@ class ResidualBlockFn(Function):
                 g_short = dz
                 # the dependent chain first (the host is what the main stream waits for in the late
                 # layers: issuing the side-stream work first left 40-140 us holes in front of the prep kernel)
+                pre = _side_prewait(dz.device)   # the side stream may start before the chain's next kernels finish
                 dz, fused = _bn3_linear_dgrad(g_short, inp, w, coef_t, ys[i - 1],
                                               cs[i - 1].data_ptr() + 8 * inp.shape[1])
-                dw = _bn3_linear_wgrad(g_short, inp, w, coef_t)
+                dw = _bn3_linear_wgrad(g_short, inp, w, coef_t, prewaited=pre)
                 put(i, dw, dg, db)
                 _flush_notifications()
                 continue
             dy, dg, db, g = _unit_bwd(dz, ys[i], zs[i], gam, bet, cs[i], mask, last, partial=fused)
             if last:
                 g_short = g
-            dw = _conv_wgrad(dy, inp, w, strides[i], pads[i])
-            put(i, dw, dg, db)
             if i > 0:
+                # chain first: the side stream is ordered behind dy now (prewait), the next kernel
+                # of the dependent chain is issued, and only then the weight-gradient kernels - in
+                # the late layers the host is what the main stream waits for (40-55 us holes in
+                # front of every backward-data kernel otherwise, profiles/r2_notes.md)
+                pre = _side_prewait(dy.device)
                 if _FUSE_BN_REDUCE["on"]:
                     dz, fused = _conv_dgrad_bn(dy, w, inp.shape, strides[i], pads[i], ys[i - 1],
                                                cs[i - 1].data_ptr() + 8 * inp.shape[1])
                 else:
                     dz, fused = _conv_dgrad(dy, w, inp.shape, strides[i], pads[i]), None
+                dw = _conv_wgrad(dy, inp, w, strides[i], pads[i], prewaited=pre)
+                put(i, dw, dg, db)
                 _flush_notifications()  # the chain's next kernel is queued: now talk to the exchange
             else:
+                dw = _conv_wgrad(dy, inp, w, strides[i], pads[i])
+                put(i, dw, dg, db)
                 addend, sub2 = g_short, False
                 if has_ds:
                     wd, gd, bd = groups[units][0], groups[units][1], groups[units][2]
