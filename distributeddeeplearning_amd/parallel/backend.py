@@ -111,6 +111,12 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
 
             engine = "native" if (want == "rccl" and _native.engine_lib() is not None) else "torch"
         _S.engine = engine
+        if cfg.cycle_time_ms:
+            import warnings
+
+            warnings.warn("HVD_CYCLE_TIME / HOROVOD_CYCLE_TIME=%g ms has no effect: gradient buckets are "
+                          "planned statically and launched the moment their last gradient arrives "
+                          "(there is no negotiation cycle to pace)" % cfg.cycle_time_ms)
         force = bool(cfg.force_collectives)
         if (world > 1 or force) and engine == "native":
             from .comm import NativeComm

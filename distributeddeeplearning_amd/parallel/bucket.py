@@ -221,6 +221,8 @@ class GradArena:
                             pv.copy_(p)
                         p.data = pv
                     gv = _shaped_view(self.grads[dt], seg, p)
+                    if gv.dtype != p.dtype and hasattr(p, "grad_dtype"):
+                        p.grad_dtype = gv.dtype   # torch >= 2.9 checks .grad against it (HVD_COMM_DTYPE=fp32)
                     p.grad = gv
                     self.views[id(p)] = gv
                     self.param_of_segment[(dt, seg.offset)] = p

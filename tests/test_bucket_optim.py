@@ -259,3 +259,26 @@ def test_graph_step_runs_eagerly_when_momentum_is_corrected():
     opt.param_groups[0]["momentum"] = 0.9
     opt.param_groups[0]["lr"] = 0.5           # the learning rate alone does not force eager steps
     assert gs._hyper() == before
+
+
+def test_comm_dtype_fp32_keeps_gradient_arenas_in_fp32(monkeypatch):
+    """HVD_COMM_DTYPE=fp32: bf16 parameters, fp32 gradient arena (= all-reduce buffer and the
+    accumulator of backward_passes_per_step), fp32 masters; the update equals fp32 SGD."""
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    monkeypatch.setenv("HVD_COMM_DTYPE", "fp32")
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(16, 8)
+    lin.weight.data = lin.weight.data.to(torch.bfloat16)
+    opt = FusedSGD(lin.named_parameters(), lr=0.1, momentum=0.9)
+    assert opt.arena.grads[torch.bfloat16].dtype == torch.float32
+    assert opt.arena.params[torch.bfloat16].dtype == torch.bfloat16
+    w0 = lin.weight.detach().float().clone()
+    g = torch.randn(8, 16) * 1e-3          # below bf16 resolution of the weights: must not be lost
+    opt.zero_grad()
+    opt.arena.ensure_view(lin.weight).copy_(g)
+    assert lin.weight.grad.dtype == torch.float32
+    opt.step()
+    seg = opt.arena.plans[torch.bfloat16].segments[0]
+    master = opt.master[torch.bfloat16][seg.offset: seg.offset + seg.numel].view(8, 16)
+    assert torch.allclose(master, w0 - 0.1 * g, atol=1e-7)

@@ -839,3 +839,55 @@ def test_device_prefetcher_uploads_and_converts_on_a_copy_stream():
     # fp32 compute dtype: no kernel, same values
     for (a, _), (c, _) in zip(u8, DevicePrefetcher(u8, DEV, dtype=torch.float32)):
         assert torch.allclose(c.cpu(), (a.float() / 255.0 - mean) / sd, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(1000, 256, 64, 64), (6272, 1024, 256, 256), (300, 2048, 512, 512)])
+def test_conv_igemm_two_segment_gemm_with_bias(shape):
+    """conv_igemm DUAL: y = x w^T + x2 w2^T + bias in one launch (the input gradient of the
+    BatchNorm-by-linearity path), every tile configuration the bottlenecks use."""
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    _hip()
+    M, C, C2, N = shape
+    g = torch.Generator(device=DEV).manual_seed(M)
+    x = torch.randn((M, C), generator=g, device=DEV).to(BF)
+    x2 = torch.randn((M, C2), generator=g, device=DEV).to(BF)
+    w = (torch.randn((N, C), generator=g, device=DEV) / math.sqrt(C)).to(BF)
+    w2 = (torch.randn((N, C2), generator=g, device=DEV) / math.sqrt(C2)).to(BF)
+    bias = torch.randn(N, generator=g, device=DEV)
+    y = torch.empty((M, N), dtype=BF, device=DEV)
+    K.conv_igemm(x, (M, 1, 1, C, C, C, C, x.numel()), w, y, N, 1, 1, 1, 0, 0, 1, 1, 1,
+                 x2=x2, w2=w2, c2=C2, bias=bias)
+    ref = x.float() @ w.float().t() + x2.float() @ w2.float().t() + bias
+    assert relerr(y, ref) < 1.5e-2 and rms_relerr(y, ref) < 4e-3
+
+
+def test_bn3_by_linearity_equals_materialised_gradient():
+    """The same chain of bottlenecks with DDL_BN3_LINEAR on and off: input gradient, every weight
+    gradient and every BatchNorm gradient agree to bf16 accuracy."""
+    from distributeddeeplearning_amd.models import resnet50
+    from distributeddeeplearning_amd.ops import functional as ops
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    hip = _hip()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = torch.rand((16, 3, 96, 96), generator=g).to(DEV).to(BF).contiguous(memory_format=CL)
+    y = torch.randint(0, 100, (16,), generator=g).to(DEV)
+
+    def run(linear):
+        hip.reset_caches()
+        hip._BN3_LINEAR["on"] = linear
+        torch.manual_seed(0)
+        model = resnet50(num_classes=128).to_compute(torch.device(DEV), BF).train()
+        opt = FusedSGD(model.named_parameters(), lr=0.0, momentum=0.0)
+        opt.zero_grad()
+        ops.softmax_cross_entropy(model(x), y).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.float().clone() for n, p in model.named_parameters()}
+
+    try:
+        a, b = run(True), run(False)
+    finally:
+        hip._BN3_LINEAR["on"] = True
+    worst = max((rms_relerr(a[n], b[n]), n) for n in a if float(b[n].abs().max()) > 0)
+    assert worst[0] < 3e-2, worst

@@ -393,3 +393,16 @@ def test_resnet50_batch_1408_of_replicated_images_equals_batch_128():
     assert torch.allclose(rmbig, rmref, rtol=1e-3, atol=1e-5)
     worst = max((rms_relerr(gbig[n], gref[n]), n) for n in gref if float(gref[n].abs().max()) > 0)
     assert worst[0] < 3e-2, worst
+
+
+def test_training_with_fp32_gradient_arenas_matches_bf16_arenas(monkeypatch):
+    """HVD_COMM_DTYPE=fp32 on the HIP path: the weight-gradient reduction writes fp32 into the arena
+    (the all-reduce buffer), the fused SGD reads fp32 gradients for bf16 parameters."""
+    from distributeddeeplearning_amd.models import resnet18
+
+    ref = _trajectory(resnet18, 8, 64, 64, 16, hip_path=True)
+    monkeypatch.setenv("HVD_COMM_DTYPE", "fp32")
+    got = _trajectory(resnet18, 8, 64, 64, 16, hip_path=True)
+    assert all(math.isfinite(v) for v in got), got
+    assert max(abs(a - b) / max(abs(b), 0.5) for a, b in zip(got, ref)) < 0.05, (got, ref)
+    assert got[-1] < 0.8 * got[0]
