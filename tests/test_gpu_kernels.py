@@ -863,31 +863,55 @@ def test_conv_igemm_two_segment_gemm_with_bias(shape):
 
 
 def test_bn3_by_linearity_equals_materialised_gradient():
-    """The same chain of bottlenecks with DDL_BN3_LINEAR on and off: input gradient, every weight
-    gradient and every BatchNorm gradient agree to bf16 accuracy."""
-    from distributeddeeplearning_amd.models import resnet50
+    """The same chain of three bottlenecks with DDL_BN3_LINEAR on and off: input gradient, every
+    weight gradient and every BatchNorm gradient agree to bf16 accuracy (the first two blocks take
+    the linear path, the last one - unmasked gradient - never does)."""
+    from distributeddeeplearning_amd.models.resnet import Bottleneck, _block_spec
     from distributeddeeplearning_amd.ops import functional as ops
-    from distributeddeeplearning_amd.optim import FusedSGD
 
     hip = _hip()
-    g = torch.Generator(device="cpu").manual_seed(4)
-    x = torch.rand((16, 3, 96, 96), generator=g).to(DEV).to(BF).contiguous(memory_format=CL)
-    y = torch.randint(0, 100, (16,), generator=g).to(DEV)
+
+    def make():
+        torch.manual_seed(7)
+        ms = [Bottleneck(128, 64, 2, True, False), Bottleneck(256, 64, 1, False, False),
+              Bottleneck(256, 64, 1, False, False)]
+        for m in ms:
+            m.to(DEV).train()
+            for mod in m.modules():
+                if hasattr(mod, "kernel"):
+                    mod.weight.data = mod.weight.data.to(BF).contiguous(memory_format=CL)
+        return ms
+
+    x0 = torch.relu(rand_nhwc(8, 128, 28, 28, seed=51))
+    gout = rand_nhwc(8, 256, 14, 14, seed=52)
+    used = {"n": 0}
+    real = hip._bn3_linear_dgrad
+
+    def counting(*a, **k):
+        used["n"] += 1
+        return real(*a, **k)
 
     def run(linear):
         hip.reset_caches()
+        ms = make()
+        x = x0.detach().clone().requires_grad_(True)
         hip._BN3_LINEAR["on"] = linear
-        torch.manual_seed(0)
-        model = resnet50(num_classes=128).to_compute(torch.device(DEV), BF).train()
-        opt = FusedSGD(model.named_parameters(), lr=0.0, momentum=0.0)
-        opt.zero_grad()
-        ops.softmax_cross_entropy(model(x), y).backward()
-        torch.cuda.synchronize()
-        return {n: p.grad.float().clone() for n, p in model.named_parameters()}
+        hip._bn3_linear_dgrad = counting
+        try:
+            specs = [_block_spec(m.pairs(), m.downsample) for m in ms]
+            out = ops.residual_chain(x, specs, True, 0.1, 1e-5)
+            out.backward(gout)
+            torch.cuda.synchronize()
+        finally:
+            hip._BN3_LINEAR["on"] = True
+            hip._bn3_linear_dgrad = real
+        names = [n for m in ms for n, _ in m.named_parameters()]
+        return x.grad, names, [p.grad.float() for m in ms for p in m.parameters()]
 
-    try:
-        a, b = run(True), run(False)
-    finally:
-        hip._BN3_LINEAR["on"] = True
-    worst = max((rms_relerr(a[n], b[n]), n) for n in a if float(b[n].abs().max()) > 0)
-    assert worst[0] < 3e-2, worst
+    dx_a, names, g_a = run(True)
+    assert used["n"] == 2, used
+    dx_b, _, g_b = run(False)
+    assert used["n"] == 2
+    assert rms_relerr(dx_a, dx_b) < 1e-2
+    for n, a, b in zip(names, g_a, g_b):
+        assert rms_relerr(a, b) < 1.5e-2, (n, rms_relerr(a, b))
