@@ -682,7 +682,12 @@ def _unit_bwd(dz, y, z, gamma, beta, coeffs, mask, want_g, partial=None):
 # narrow activation, fixed up in the split-K reduction.  Costed in profiles/r1_notes.md (the apply
 # pass alone: 1.57 ms of the 19.2 ms step); numerics in benchmarks/bn_linearity_check.py and the
 # block / trajectory tests.  DDL_BN3_LINEAR=0 restores the materialised dy3.
-_BN3_LINEAR = {"on": _os.environ.get("DDL_BN3_LINEAR", "1") != "0"}
+_BN3_LINEAR = {"on": _os.environ.get("DDL_BN3_LINEAR", "1") != "0",
+               "max_c2": int(_os.environ.get("DDL_BN3_LINEAR_MAX_C2", "256"))}   # layer 4 (512 -> 2048 at 7x7) measured faster with dy3 materialised
+# the same for the projection shortcut's BatchNorm, where the conv's input is narrow enough for the
+# Cin x Cin Gram / Q matrices and the longer reduction to cost less than the pass they replace
+_DS_LINEAR = {"on": _os.environ.get("DDL_DS_LINEAR", "1") != "0",
+              "max_cin": int(_os.environ.get("DDL_DS_LINEAR_MAX_CIN", "64"))}
 
 
 def _unit_coef(dz, y, gamma, beta, coeffs, partial):
@@ -717,7 +722,7 @@ def _bn3_linear_ok(w, stride, padding, g, z2):
     Kc, C2, R, S = w.shape
     return _BN3_LINEAR["on"] and not _WT_KRSC and R == 1 and S == 1 and stride == 1 and padding == 0 and \
         C2 % 64 == 0 and Kc % 32 == 0 and Kc <= 2048 and g.shape[1] == Kc and z2.shape[1] == C2 and \
-        g.shape[2:] == z2.shape[2:]
+        g.shape[2:] == z2.shape[2:] and C2 <= _BN3_LINEAR["max_c2"]
 
 
 def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
@@ -735,9 +740,12 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
     K.bn_lin_prep(wt3, C, coef_t.data_ptr(), C, C2, b1, a2, bias)
     # Q[k][j] = sum_c cb[c] w[c][k] w[c][j]: a2 (rows k) times wt3^T, a C2 x C2 GEMM over C
     K.conv_igemm(a2, (C2, 1, 1, C, C, C, C, a2.numel()), wt3, q, C2, 1, 1, 1, 0, 0, 1, 1, 1)
+    g2 = _empty_nhwc(B, C2, H, W, dev)
+    if y_prev is None:   # plain store (projection shortcut: the result is the addend of the block-input gradient)
+        K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, x2=z2, w2=q, c2=C2, bias=bias)
+        return g2, None
     T = K.conv_tiles_m_bwd(B * H * W, H, W, 1, 1)
     partial = torch.empty((T, 2, C2), dtype=torch.float32, device=dev)
-    g2 = _empty_nhwc(B, C2, H, W, dev)
     K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, stats=partial, ep_y=y_prev,
                  ep_fcoef=fcoef_prev, x2=z2, w2=q, c2=C2, bias=bias)
     return g2, partial
@@ -1214,15 +1222,31 @@ class ResidualBlockFn(Function):
                 if has_ds:
                     wd, gd, bd = groups[units][0], groups[units][1], groups[units][2]
                     yd, cd = saved[1 + 3 * units], saved[2 + 3 * units]
-                    dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False,
-                                                 partial=fused_ds)
-                    dwd = _conv_wgrad(dyd, x, wd, ds_stride, 0)
-                    put(units, dwd, dgd, dbd)
-                    if ctx.needs_input_grad[0]:
-                        if ds_stride == 2 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
-                            addend, sub2 = _conv_dgrad_1x1s2_compact(dyd, wd), True
-                        else:
-                            addend = _conv_dgrad(dyd, wd, x.shape, ds_stride, 0)
+                    even = x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                    if fused_ds is not None and ctx.needs_input_grad[0] and _DS_LINEAR["on"] and \
+                            (ds_stride == 1 or (ds_stride == 2 and even)) and _BN3_LINEAR["on"] and \
+                            not _WT_KRSC and wd.shape[2] == 1 and wd.shape[1] % 64 == 0 and \
+                            wd.shape[0] % 32 == 0 and wd.shape[0] <= 2048 and g_short.shape[1] == wd.shape[0] and \
+                            wd.shape[1] <= _DS_LINEAR["max_cin"]:
+                        # the projection shortcut's BatchNorm by linearity as well (yd = x_s Wd^T with
+                        # x_s the input at the pixels the strided 1x1 conv visits): dyd never exists
+                        xs = x if ds_stride == 1 else x[:, :, ::2, ::2].contiguous(memory_format=_CL)
+                        coef_d, dgd, dbd = _unit_coef(g_short, yd, gd, bd, cd, fused_ds)
+                        pre = _side_prewait(g_short.device)
+                        addend, _ = _bn3_linear_dgrad(g_short, xs, wd, coef_d, None, None)
+                        sub2 = ds_stride == 2
+                        dwd = _bn3_linear_wgrad(g_short, xs, wd, coef_d, prewaited=pre)
+                        put(units, dwd, dgd, dbd)
+                    else:
+                        dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False,
+                                                     partial=fused_ds)
+                        dwd = _conv_wgrad(dyd, x, wd, ds_stride, 0)
+                        put(units, dwd, dgd, dbd)
+                        if ctx.needs_input_grad[0]:
+                            if ds_stride == 2 and even:
+                                addend, sub2 = _conv_dgrad_1x1s2_compact(dyd, wd), True
+                            else:
+                                addend = _conv_dgrad(dyd, wd, x.shape, ds_stride, 0)
                 if ctx.needs_input_grad[0]:
                     bn_y = link_in.y if (premask_in and link_in is not None and
                                          _FUSE_BN_REDUCE["on"]) else None

@@ -417,9 +417,11 @@ def test_residual_chain_matches_unchained_blocks():
         o_d, dx_d, g_d = run(True)
     finally:
         hip._FUSE_DS_REDUCE["on"] = True
-    assert rms_relerr(dx_d, dx_b) < 2e-3
+    # (with the fused partials the projection's BatchNorm also goes by linearity, without them its dy is
+    # materialised: same math, bf16 roundings in other places)
+    assert rms_relerr(dx_d, dx_b) < 1e-2
     for a, b in zip(g_d, g_b):
-        assert rms_relerr(a, b) < 2e-3
+        assert rms_relerr(a, b) < 1e-2
     # identical math up to the summation order of the BatchNorm partials (bf16 re-rounding of
     # dy then propagates): compare in rms
     assert rms_relerr(dx_b, dx_a) < 1e-2
@@ -909,9 +911,9 @@ def test_bn3_by_linearity_equals_materialised_gradient():
         return x.grad, names, [p.grad.float() for m in ms for p in m.parameters()]
 
     dx_a, names, g_a = run(True)
-    assert used["n"] == 2, used
+    assert used["n"] == 3, used     # two main-path BatchNorms + the first block's projection shortcut
     dx_b, _, g_b = run(False)
-    assert used["n"] == 2
+    assert used["n"] == 3
     assert rms_relerr(dx_a, dx_b) < 1e-2
     for n, a, b in zip(names, g_a, g_b):
         assert rms_relerr(a, b) < 1.5e-2, (n, rms_relerr(a, b))
