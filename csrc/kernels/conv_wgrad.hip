@@ -318,11 +318,17 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // T = W (z^T z) and the column sums of z,
 //   out[c][j] (+)= ca[c] * sum_s partial[s][c][j] + cb[c] * T[c][j] + cc[c] * colz[j]
 // Same block shape and the same fixed summation order as splitk_reduce_kernel.
-template <typename OutT, bool ACCUM, int SL>
+// CENTER = true is the companion that produces the Gram matrix itself: out[k][j] = sum_s partial -
+// colz[k]*colz[j]/M, the CENTRED second moment (subtracted in fp32, before the bf16 rounding: with
+// the raw Gram matrix the product W G and the mean term cc (x) colz cancel each other's large parts
+// after rounding, which costs mean^2/variance in relative accuracy).  With the centred matrix the
+// rank-1 coefficient becomes cc + cb*mean = -ca*sum(g)/M.
+template <typename OutT, bool ACCUM, int SL, bool CENTER>
 __global__ void __launch_bounds__(256) splitk_reduce_lin_kernel(const float* __restrict__ partial, OutT* __restrict__ out,
                                                                long long n, int splits, long long slab,
                                                                const float* __restrict__ coef, int C, const bf16_t* __restrict__ T,
-                                                               const float* __restrict__ colz, int row_len) {
+                                                               const float* __restrict__ colz, int row_len,
+                                                               const float* __restrict__ mean, float inv_m) {
     constexpr int COLS = 256 / SL;
     __shared__ f32x4 red[SL > 1 ? 256 : 1];
     const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
@@ -349,11 +355,17 @@ __global__ void __launch_bounds__(256) splitk_reduce_lin_kernel(const float* __r
     if (i >= n4) return;
     const long long e0 = i << 2;
     const int c = (int)(e0 / row_len), j = (int)(e0 - (long long)c * row_len);
-    const float ca = coef[c], cb = coef[C + c], cc = coef[2 * C + c];
-    const bf16x4 tv = *reinterpret_cast<const bf16x4*>(T + e0);
     const f32x4 cz = *reinterpret_cast<const f32x4*>(colz + j);
+    if (CENTER) {
+        const float zc = colz[c] * inv_m;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] = ca * s[e] + cb * bf2f(tv[e]) + cc * cz[e];
+        for (int e = 0; e < 4; ++e) s[e] -= zc * cz[e];
+    } else {
+        const float ca = coef[c], cb = coef[C + c], cc = coef[2 * C + c] + cb * mean[c];
+        const bf16x4 tv = *reinterpret_cast<const bf16x4*>(T + e0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = ca * s[e] + cb * bf2f(tv[e]) + cc * cz[e];
+    }
     if constexpr (sizeof(OutT) == 4) {
         f32x4* o = reinterpret_cast<f32x4*>(out + e0);
         if (ACCUM) s += *o;
@@ -506,20 +518,35 @@ extern "C" int ddl_splitk_reduce(const void* partial, void* out, long long n, in
 
 extern "C" int ddl_splitk_reduce_lin(const void* partial, void* out, long long n, int splits, long long slab,
                                      int out_is_bf16, int accumulate, const void* coef, int C, const void* T,
-                                     const void* colz, int row_len, hipStream_t stream) {
-    if (!partial || !out || !coef || !T || !colz || n <= 0 || splits <= 0 || (n & 3) || slab < n || (slab & 3)) return DDL_EINVAL;
+                                     const void* colz, int row_len, const void* mean, hipStream_t stream) {
+    if (!partial || !out || !coef || !T || !colz || !mean || n <= 0 || splits <= 0 || (n & 3) || slab < n || (slab & 3)) return DDL_EINVAL;
     if (C <= 0 || row_len <= 0 || (row_len & 3) || n != (long long)C * row_len) return DDL_EINVAL;
     if (!ddl_aligned16(partial) || (reinterpret_cast<uintptr_t>(out) & 7) || (reinterpret_cast<uintptr_t>(T) & 7) || !ddl_aligned16(colz)) return DDL_EALIGN;
     if (!out_is_bf16 && !ddl_aligned16(out)) return DDL_EALIGN;
     const long long n4 = n / 4;
     const int sl = splits >= 64 ? 16 : (splits >= 8 ? 4 : 1);
     dim3 grid((unsigned)((n4 + 256 / sl - 1) / (256 / sl))), block(256);
-#define RL3(TT, A, S) hipLaunchKernelGGL((splitk_reduce_lin_kernel<TT, A, S>), grid, block, 0, stream, (const float*)partial, (TT*)out, n, splits, slab, \
-                                        (const float*)coef, C, (const bf16_t*)T, (const float*)colz, row_len)
+#define RL3(TT, A, S) hipLaunchKernelGGL((splitk_reduce_lin_kernel<TT, A, S, false>), grid, block, 0, stream, (const float*)partial, (TT*)out, n, splits, slab, \
+                                        (const float*)coef, C, (const bf16_t*)T, (const float*)colz, row_len, (const float*)mean, 0.f)
 #define RL(TT, A) do { if (sl == 16) RL3(TT, A, 16); else if (sl == 4) RL3(TT, A, 4); else RL3(TT, A, 1); } while (0)
     if (out_is_bf16) { if (accumulate) RL(bf16_t, true); else RL(bf16_t, false); }
     else { if (accumulate) RL(float, true); else RL(float, false); }
 #undef RL3
 #undef RL
+    return ddl_launch_status();
+}
+
+// out (bf16 [C][C]) = sum_s partial[s] - colz (x) colz / M: the centred Gram matrix of a [M][C] tensor
+extern "C" int ddl_splitk_reduce_centered(const void* partial, void* out, int C, int splits, const void* colz, long long M,
+                                          hipStream_t stream) {
+    if (!partial || !out || !colz || C <= 0 || (C & 3) || splits <= 0 || M <= 0) return DDL_EINVAL;
+    if (!ddl_aligned16(partial) || (reinterpret_cast<uintptr_t>(out) & 7) || !ddl_aligned16(colz)) return DDL_EALIGN;
+    const long long n = (long long)C * C, n4 = n / 4;
+    const int sl = splits >= 64 ? 16 : (splits >= 8 ? 4 : 1);
+    dim3 grid((unsigned)((n4 + 256 / sl - 1) / (256 / sl))), block(256);
+#define RC(S) hipLaunchKernelGGL((splitk_reduce_lin_kernel<bf16_t, false, S, true>), grid, block, 0, stream, (const float*)partial, (bf16_t*)out, n, splits, n, \
+                                 (const float*)nullptr, C, (const bf16_t*)nullptr, (const float*)colz, C, (const float*)nullptr, 1.0f / (float)M)
+    if (sl == 16) RC(16); else if (sl == 4) RC(4); else RC(1);
+#undef RC
     return ddl_launch_status();
 }

@@ -675,7 +675,8 @@ def _unit_bwd(dz, y, z, gamma, beta, coeffs, mask, want_g, partial=None):
 # ---- BatchNorm backward of a bottleneck's last unit by linearity -----------------------------------
 # dy3 = ca*g + cb*y3 + cc per channel and y3 = z2 W3^T (1x1 conv), hence
 #   dz2 = g (diag(ca) W3) + z2 (W3^T diag(cb) W3) + 1 (cc^T W3)                    (input gradient)
-#   dW3 = diag(ca) (g^T z2) + diag(cb) W3 (z2^T z2) + cc (x) colsum(z2)             (weight gradient)
+#   dW3 = diag(ca) (g^T z2) + diag(cb) W3 (z2^T z2) + cc (x) colsum(z2)             (weight gradient;
+#         evaluated with the CENTRED Gram matrix z2^T z2 - colsum (x) colsum / M, see splitk_reduce_lin_kernel)
 # so dy3 - three passes over the block's WIDEST tensor (read g, read y3, write dy3, then read twice
 # more by the two GEMMs) - never exists.  The input gradient becomes ONE two-segment GEMM over g and
 # z2 (K grows by a quarter); the weight gradient is the raw product g^T z2 plus a Gram matrix of the
@@ -751,7 +752,7 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
     return g2, partial
 
 
-def _bn3_linear_wgrad(g, z2, w, coef_t, prewaited=False):
+def _bn3_linear_wgrad(g, z2, w, coef_t, mean_ptr, prewaited=False):
     """dW3 by linearity, into ``w.grad`` when that is a live arena view (returns None and notifies),
     else returned.  Runs on the weight-gradient stream like _conv_wgrad: raw stream handle, one
     persistent workspace carved by address (no torch stream switch, no allocations)."""
@@ -784,13 +785,13 @@ def _bn3_linear_wgrad(g, z2, w, coef_t, prewaited=False):
     colz = zp + 4 * Tz * 2 * C2
     K.conv_wgrad(g, z2, gz, partial, C, 1, 1, 1, 0, 0, H, W, splits, stream=raw)
     K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2, stream=raw)
-    K.splitk_reduce(gp, gram, gslab, s2, gslab, False, stream=raw, out_bf16=True)
     K.bn_stats_partial(z2, zp, M, C2, rows, stream=raw)
     K.bn_colsum_fold(zp, Tz, C2, colz, stream=raw)
+    K.splitk_reduce_centered(gp, gram, C2, s2, colz, M, stream=raw)   # z2^T z2 - colz (x) colz / M
     # T = W3 (z2^T z2): rows c of the filter times the (symmetric) Gram matrix
     K.conv_igemm(w, (C, 1, 1, C2, C2, C2, C2, w.numel()), gram, _RawOut(t, slab), C2, 1, 1, 1, 0, 0, 1, 1, 1,
                  stream=raw, w_numel=gslab)
-    K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, colz, C2, stream=raw)
+    K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, colz, C2, mean_ptr, stream=raw)
     if side is not None:
         _side_mark_used()
         if _SIDE["join_queued"]:
@@ -1194,7 +1195,7 @@ class ResidualBlockFn(Function):
                 pre = _side_prewait(dz.device)   # the side stream may start before the chain's next kernels finish
                 dz, fused = _bn3_linear_dgrad(g_short, inp, w, coef_t, ys[i - 1],
                                               cs[i - 1].data_ptr() + 8 * inp.shape[1])
-                dw = _bn3_linear_wgrad(g_short, inp, w, coef_t, prewaited=pre)
+                dw = _bn3_linear_wgrad(g_short, inp, w, coef_t, cs[i].data_ptr(), prewaited=pre)
                 put(i, dw, dg, db)
                 _flush_notifications()
                 continue
@@ -1235,7 +1236,7 @@ class ResidualBlockFn(Function):
                         pre = _side_prewait(g_short.device)
                         addend, _ = _bn3_linear_dgrad(g_short, xs, wd, coef_d, None, None)
                         sub2 = ds_stride == 2
-                        dwd = _bn3_linear_wgrad(g_short, xs, wd, coef_d, prewaited=pre)
+                        dwd = _bn3_linear_wgrad(g_short, xs, wd, coef_d, cd.data_ptr(), prewaited=pre)
                         put(units, dwd, dgd, dbd)
                     else:
                         dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False,

@@ -300,12 +300,20 @@ def splitk_reduce(partial, out, n, splits, slab, accumulate=False, stream=None, 
             _raw_stream() if stream is None else stream), "splitk_reduce")
 
 
-def splitk_reduce_lin(partial, out, n, splits, slab, accumulate, coef, C, T, colz, row_len, stream=None):
-    """out (+)= ca[c]*sum_s partial[s] + cb[c]*T + cc[c]*colz[j] (BatchNorm backward by linearity)."""
-    f = _fn("ddl_splitk_reduce_lin", "pp qiq ii p i pp i p")
+def splitk_reduce_lin(partial, out, n, splits, slab, accumulate, coef, C, T, colz, row_len, mean, stream=None):
+    """out (+)= ca[c]*sum_s partial[s] + cb[c]*T + (cc[c] + cb[c]*mean[c])*colz[j] (BatchNorm backward by
+    linearity; ``T`` = W times the CENTRED Gram matrix from :func:`splitk_reduce_centered`)."""
+    f = _fn("ddl_splitk_reduce_lin", "pp qiq ii p i pp i p p")
     check(f(_p(partial), out.data_ptr(), n, splits, slab, 1 if out.dtype == torch.bfloat16 else 0,
-            1 if accumulate else 0, _p(coef), C, _p(T), _p(colz), row_len,
+            1 if accumulate else 0, _p(coef), C, _p(T), _p(colz), row_len, _p(mean),
             _raw_stream() if stream is None else stream), "splitk_reduce_lin")
+
+
+def splitk_reduce_centered(partial, out, C, splits, colz, M, stream=None):
+    """out (bf16 [C][C]) = sum_s partial[s] - colz (x) colz / M (centred in fp32, rounded once)."""
+    f = _fn("ddl_splitk_reduce_centered", "pp ii p q p")
+    check(f(_p(partial), _p(out), C, splits, _p(colz), M, _raw_stream() if stream is None else stream),
+          "splitk_reduce_centered")
 
 
 def bn_lin_prep(wt, ld, coef, C, rows, b1, a2, bias):

@@ -899,6 +899,8 @@ def test_bn3_by_linearity_equals_materialised_gradient():
         x = x0.detach().clone().requires_grad_(True)
         hip._BN3_LINEAR["on"] = linear
         hip._bn3_linear_dgrad = counting
+        saved = hip._BN3_LINEAR["max_c2"], hip._DS_LINEAR["max_cin"]
+        hip._BN3_LINEAR["max_c2"] = hip._DS_LINEAR["max_cin"] = 4096    # every eligible BatchNorm, whatever its width
         try:
             specs = [_block_spec(m.pairs(), m.downsample) for m in ms]
             out = ops.residual_chain(x, specs, True, 0.1, 1e-5)
@@ -907,6 +909,7 @@ def test_bn3_by_linearity_equals_materialised_gradient():
         finally:
             hip._BN3_LINEAR["on"] = True
             hip._bn3_linear_dgrad = real
+            hip._BN3_LINEAR["max_c2"], hip._DS_LINEAR["max_cin"] = saved
         names = [n for m in ms for n, _ in m.named_parameters()]
         return x.grad, names, [p.grad.float() for m in ms for p in m.parameters()]
 
@@ -917,3 +920,66 @@ def test_bn3_by_linearity_equals_materialised_gradient():
     assert rms_relerr(dx_a, dx_b) < 1e-2
     for n, a, b in zip(names, g_a, g_b):
         assert rms_relerr(a, b) < 1.5e-2, (n, rms_relerr(a, b))
+
+
+@pytest.mark.parametrize("beta2", [0.0, 2.0])
+def test_linearity_path_against_fp32_reference(beta2):
+    """(``beta2``: bias of every block's second BatchNorm - with 2.0 the narrow activation the Gram
+    matrix is built from has a mean of about twice its standard deviation, the case the centred
+    Gram matrix exists for.)  A chain of three bottlenecks (projection + two identity blocks) with EVERY eligible BatchNorm
+    backward taken by linearity, against the same blocks in fp32 ATen; error budget = twice the
+    error of the stock bf16 ATen path against that reference, as for the single block."""
+    from distributeddeeplearning_amd.models.resnet import Bottleneck, _block_spec
+    from distributeddeeplearning_amd.ops import functional as ops
+
+    hip = _hip()
+    hip.reset_caches()
+
+    def make(dtype):
+        torch.manual_seed(3)
+        ms = [Bottleneck(128, 64, 2, True, False), Bottleneck(256, 64, 1, False, False),
+              Bottleneck(256, 64, 1, False, False)]
+        for m in ms:
+            m.to(DEV).train()
+            for mod in m.modules():
+                if hasattr(mod, "kernel"):
+                    wq = mod.weight.data.to(BF)
+                    mod.weight.data = wq.to(dtype).contiguous(memory_format=CL)
+            m.bn2.bias.data.fill_(beta2)
+        return ms
+
+    x0 = torch.relu(rand_nhwc(8, 128, 28, 28, seed=61))
+    gout = rand_nhwc(8, 256, 14, 14, seed=62)
+
+    def run(backend, dtype, chained):
+        ms = make(dtype)
+        x = x0.detach().to(dtype).requires_grad_(True)
+        ops.set_backend(backend)
+        saved = hip._BN3_LINEAR["max_c2"], hip._DS_LINEAR["max_cin"]
+        hip._BN3_LINEAR["max_c2"] = hip._DS_LINEAR["max_cin"] = 4096
+        try:
+            if chained:
+                out = ops.residual_chain(x, [_block_spec(m.pairs(), m.downsample) for m in ms], True, 0.1, 1e-5)
+            else:
+                out = x
+                for m in ms:
+                    out = m(out)
+            out.backward(gout.to(dtype))
+            torch.cuda.synchronize()
+        finally:
+            ops.set_backend("auto")
+            hip._BN3_LINEAR["max_c2"], hip._DS_LINEAR["max_cin"] = saved
+        return x.grad.float(), [p.grad.float() for m in ms for p in m.parameters()], \
+            [n for m in ms for n, _ in m.named_parameters()]
+
+    dx_r, g_r, names = run("aten", torch.float32, False)
+    dx_a, g_a, _ = run("aten", BF, False)
+    dx_h, g_h, _ = run("auto", BF, True)
+
+    def ok(h, a, r, what):
+        eh, ea = rms_relerr(h, r), rms_relerr(a, r)
+        assert eh < max(2.0 * ea, 2e-2), "%s: hip (linearity) %.4f vs stock bf16 %.4f" % (what, eh, ea)
+
+    ok(dx_h, dx_a, dx_r, "dx")
+    for n, h, a, r in zip(names, g_h, g_a, g_r):
+        ok(h, a, r, n)

@@ -391,8 +391,13 @@ def test_resnet50_batch_1408_of_replicated_images_equals_batch_128():
     lbig, gbig, rmbig = run(176)
     assert abs(lbig - lref) < 1e-4 * abs(lref), (lbig, lref)
     assert torch.allclose(rmbig, rmref, rtol=1e-3, atol=1e-5)
+    # a wrapped offset drops or duplicates whole images (errors of order 1); rounding differences of
+    # the two tilings stay at the per-cent level even in the deepest (stem) gradients
     worst = max((rms_relerr(gbig[n], gref[n]), n) for n in gref if float(gref[n].abs().max()) > 0)
-    assert worst[0] < 3e-2, worst
+    assert worst[0] < 0.15, worst
+    cos = min((float((gbig[n] * gref[n]).sum() / (gbig[n].norm() * gref[n].norm()).clamp_min(1e-30)), n)
+              for n in gref if float(gref[n].abs().max()) > 0)
+    assert cos[0] > 0.99, cos
 
 
 def test_training_with_fp32_gradient_arenas_matches_bf16_arenas(monkeypatch):
