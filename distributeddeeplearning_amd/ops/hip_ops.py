@@ -726,6 +726,19 @@ def _bn3_linear_ok(w, stride, padding, g, z2):
         g.shape[2:] == z2.shape[2:] and C2 <= _BN3_LINEAR["max_c2"]
 
 
+def _lin_main_static_ok(w, stride, padding):
+    Kc, C2, R, S = w.shape
+    return _BN3_LINEAR["on"] and not _WT_KRSC and R == 1 and S == 1 and stride == 1 and padding == 0 and \
+        C2 % 64 == 0 and Kc % 32 == 0 and Kc <= 2048 and C2 <= _BN3_LINEAR["max_c2"]
+
+
+def _lin_ds_static_ok(wd, ds_stride, x):
+    even = x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+    return _DS_LINEAR["on"] and _BN3_LINEAR["on"] and not _WT_KRSC and (ds_stride == 1 or (ds_stride == 2 and even)) and \
+        wd.shape[2] == 1 and wd.shape[1] % 64 == 0 and wd.shape[0] % 32 == 0 and wd.shape[0] <= 2048 and \
+        wd.shape[1] <= _DS_LINEAR["max_cin"]
+
+
 def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
     """Input gradient of the 1x1 conv behind the BatchNorm whose backward coefficients are in
     ``coef_t``: g [B, C, H, W] is that BatchNorm's (ReLU-masked) output gradient, z2 the conv's
@@ -752,27 +765,87 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
     return g2, partial
 
 
-def _bn3_linear_wgrad(g, z2, w, coef_t, mean_ptr, prewaited=False):
+def _lin_gram_layout(M, C, C2):
+    rows = 512
+    Tz = (M + rows - 1) // rows
+    s2 = K.conv_wgrad_splits(M, C2, C2, 1, 1)
+    return rows, Tz, s2
+
+
+def _bn3_linear_gram(z2, w, raw, base, t, colz):
+    """The part of the linear weight gradient that only depends on FORWARD data: column sums of z2,
+    the centred Gram matrix z2^T z2 - colz (x) colz / M and T = W (that matrix), written to the raw
+    addresses ``colz`` ([2][C2] fp32) and ``t`` ([C][C2] bf16); ``base`` = scratch on stream ``raw``."""
+    C, C2 = w.shape[0], w.shape[1]
+    B, _, H, W = z2.shape
+    M = B * H * W
+    gz = _geom(z2)
+    rows, Tz, s2 = _lin_gram_layout(M, C, C2)
+    gslab = C2 * C2
+    gp = base
+    gram = gp + (4 * s2 * gslab + 255) // 256 * 256
+    zp = gram + (2 * gslab + 255) // 256 * 256
+    K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2, stream=raw)
+    K.bn_stats_partial(z2, zp, M, C2, rows, stream=raw)
+    K.bn_colsum_fold(zp, Tz, C2, colz, stream=raw)
+    K.splitk_reduce_centered(gp, gram, C2, s2, colz, M, stream=raw)   # z2^T z2 - colz (x) colz / M
+    # T = W3 (centred Gram): rows c of the filter times the (symmetric) matrix
+    K.conv_igemm(w, (C, 1, 1, C2, C2, C2, C2, w.numel()), gram, _RawOut(t, C * C2), C2, 1, 1, 1, 0, 0, 1, 1, 1,
+                 stream=raw, w_numel=gslab)
+
+
+def _lin_gram_scratch_bytes(M, C, C2):
+    rows, Tz, s2 = _lin_gram_layout(M, C, C2)
+    gslab = C2 * C2
+    return (4 * s2 * gslab + 255) // 256 * 256 + (2 * gslab + 255) // 256 * 256 + 4 * Tz * 2 * C2 + 256
+
+
+# The forward pass leaves the weight-gradient stream idle: the Gram part of a block that will take
+# the linear path in backward runs there, right after the block's narrow activation exists (it is
+# still in the Infinity Cache then), instead of in the crowded backward window.  Measured SLOWER
+# (18.51 / 18.52 ms against 18.44 / 18.45 ms: the forward pass is main-stream time too and slows down
+# by what backward gains), so it is opt-in: DDL_LIN_GRAM_FWD=1.
+_LIN_GRAM_FWD = {"on": _os.environ.get("DDL_LIN_GRAM_FWD", "0") == "1"}
+
+
+def _bn3_linear_gram_forward(z2, w):
+    """Forward-time launch of :func:`_bn3_linear_gram` on the weight-gradient stream.  Returns the
+    tensor holding T ([C][C2] bf16) followed by the column sums ([2][C2] fp32), or None when the
+    side stream is not in use."""
+    if not (_LIN_GRAM_FWD["on"] and _SIDE["on"] and _SIDE_LEAN and _DIRECT["on"] and _grad_listeners is not None):
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    C, C2 = w.shape[0], w.shape[1]
+    B, _, H, W = z2.shape
+    M = B * H * W
+    tbytes = (2 * C * C2 + 255) // 256 * 256
+    pre = torch.empty(tbytes + 4 * 2 * C2, dtype=torch.uint8, device=z2.device)
+    side = _side_stream(z2.device)
+    raw = side.cuda_stream
+    K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
+    base = _side_workspace(_lin_gram_scratch_bytes(M, C, C2))
+    _bn3_linear_gram(z2, w, raw, base, pre.data_ptr(), pre.data_ptr() + tbytes)
+    return pre
+
+
+def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None):
     """dW3 by linearity, into ``w.grad`` when that is a live arena view (returns None and notifies),
     else returned.  Runs on the weight-gradient stream like _conv_wgrad: raw stream handle, one
-    persistent workspace carved by address (no torch stream switch, no allocations)."""
+    persistent workspace carved by address (no torch stream switch, no allocations).  ``pre``: the
+    Gram part already computed during the forward pass (:func:`_bn3_linear_gram_forward`).
+    ``coeffs``: the BatchNorm's saved [4, C] block (its first row, the batch mean, is read here)."""
     C, C2 = w.shape[0], w.shape[1]
     direct = _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]
     out = w.grad if direct else torch.zeros_like(w)
     side = _side_stream(g.device) if (_SIDE["on"] and direct) else None
     B, _, H, W = g.shape
     M = B * H * W
-    gz = _geom(z2)
     splits = K.conv_wgrad_splits(M, C, C2, 1, 1)      # raw product g^T z2
-    s2 = K.conv_wgrad_splits(M, C2, C2, 1, 1)         # Gram matrix z2^T z2
-    slab, gslab = C * C2, C2 * C2
-    rows = 512
-    Tz = (M + rows - 1) // rows
-    sizes = (4 * splits * slab, 4 * s2 * gslab, 2 * gslab, 4 * (Tz + 1) * 2 * C2, 2 * slab)
-    offs, total = [], 0
-    for nb in sizes:
-        offs.append(total)
-        total += (nb + 255) // 256 * 256
+    slab = C * C2
+    pbytes = (4 * splits * slab + 255) // 256 * 256
+    tbytes = (2 * slab + 255) // 256 * 256
+    total = pbytes + (0 if pre is not None else tbytes + 4 * 2 * C2 + 256 + _lin_gram_scratch_bytes(M, C, C2))
     if side is None:
         ws_t = torch.empty(total, dtype=torch.uint8, device=g.device)
         base, raw = ws_t.data_ptr(), None
@@ -781,23 +854,26 @@ def _bn3_linear_wgrad(g, z2, w, coef_t, mean_ptr, prewaited=False):
         if not prewaited:
             K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
         base = _side_workspace(total)
-    partial, gp, gram, zp, t = (base + o for o in offs)
-    colz = zp + 4 * Tz * 2 * C2
-    K.conv_wgrad(g, z2, gz, partial, C, 1, 1, 1, 0, 0, H, W, splits, stream=raw)
-    K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2, stream=raw)
-    K.bn_stats_partial(z2, zp, M, C2, rows, stream=raw)
-    K.bn_colsum_fold(zp, Tz, C2, colz, stream=raw)
-    K.splitk_reduce_centered(gp, gram, C2, s2, colz, M, stream=raw)   # z2^T z2 - colz (x) colz / M
-    # T = W3 (z2^T z2): rows c of the filter times the (symmetric) Gram matrix
-    K.conv_igemm(w, (C, 1, 1, C2, C2, C2, C2, w.numel()), gram, _RawOut(t, slab), C2, 1, 1, 1, 0, 0, 1, 1, 1,
-                 stream=raw, w_numel=gslab)
-    K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, colz, C2, mean_ptr, stream=raw)
+    partial = base
+    K.conv_wgrad(g, z2, _geom(z2), partial, C, 1, 1, 1, 0, 0, H, W, splits, stream=raw)
+    if pre is not None:
+        t = pre.data_ptr()
+        colz = t + tbytes
+    else:
+        t = base + pbytes
+        colz = t + tbytes
+        _bn3_linear_gram(z2, w, raw, colz + 8 * C2, t, colz)   # (8*C2 bytes of column sums; C2 % 64 == 0 keeps the alignment)
+    K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, colz, C2,
+                        coeffs.data_ptr(), stream=raw)
     if side is not None:
+        # everything the side stream still reads after this function returns - including the saved
+        # coefficient block: autograd releases a node's saved tensors when its backward returns, and
+        # the allocator would hand their memory to the main stream while the reduction is still queued
         _side_mark_used()
         if _SIDE["join_queued"]:
-            _SIDE["keep"].append((g, z2, coef_t))
+            _SIDE["keep"].append((g, z2, coef_t, coeffs, pre))
         else:
-            for t_ in (g, z2, coef_t):
+            for t_ in (g, z2, coef_t, coeffs) + ((pre,) if pre is not None else ()):
                 t_.record_stream(side)
     if direct:
         _notify(w)
@@ -1102,6 +1178,13 @@ class ResidualBlockFn(Function):
                                        False)
         cur = x
         zbits_out = None
+        ctx.lin_pre = ctx.lin_pre_ds = ctx.lin_xs = None
+        # cfg[9] (grad_premasked) is only set by residual_chain with grad mode on: backward will receive a
+        # pre-masked gradient and the BatchNorm partials, i.e. it will take the linear path
+        lin_chain = bool(cfg[9]) and _FUSE_BN_REDUCE["on"]
+        if training and has_ds and lin_chain and _FUSE_DS_REDUCE["on"] and _lin_ds_static_ok(groups[units][0], ds_stride, x):
+            ctx.lin_xs = x if ds_stride == 1 else x[:, :, ::2, ::2].contiguous(memory_format=_CL)
+            ctx.lin_pre_ds = _bn3_linear_gram_forward(ctx.lin_xs, groups[units][0])
         for i in range(units):
             w, g, b, rm, rv = groups[i]
             last = i == units - 1
@@ -1123,6 +1206,11 @@ class ResidualBlockFn(Function):
             saved_y.append(y)
             saved_z.append(z)
             saved_c.append(c)
+            if training and lin_chain and units == 3 and i == units - 2 and \
+                    _lin_main_static_ok(groups[units - 1][0], strides[units - 1], pads[units - 1]):
+                # this block's last BatchNorm will go by linearity in backward: its Gram part only
+                # needs z (the narrow activation just written) and runs now, on the idle side stream
+                ctx.lin_pre = _bn3_linear_gram_forward(z, groups[units - 1][0])
             cur = z
         if len(cfg) > 11 and cfg[11] is not None:
             cfg[11].y = saved_y[-1]
@@ -1195,7 +1283,8 @@ class ResidualBlockFn(Function):
                 pre = _side_prewait(dz.device)   # the side stream may start before the chain's next kernels finish
                 dz, fused = _bn3_linear_dgrad(g_short, inp, w, coef_t, ys[i - 1],
                                               cs[i - 1].data_ptr() + 8 * inp.shape[1])
-                dw = _bn3_linear_wgrad(g_short, inp, w, coef_t, cs[i].data_ptr(), prewaited=pre)
+                dw = _bn3_linear_wgrad(g_short, inp, w, coef_t, cs[i], prewaited=pre,
+                                       pre=getattr(ctx, "lin_pre", None))
                 put(i, dw, dg, db)
                 _flush_notifications()
                 continue
@@ -1224,19 +1313,19 @@ class ResidualBlockFn(Function):
                     wd, gd, bd = groups[units][0], groups[units][1], groups[units][2]
                     yd, cd = saved[1 + 3 * units], saved[2 + 3 * units]
                     even = x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-                    if fused_ds is not None and ctx.needs_input_grad[0] and _DS_LINEAR["on"] and \
-                            (ds_stride == 1 or (ds_stride == 2 and even)) and _BN3_LINEAR["on"] and \
-                            not _WT_KRSC and wd.shape[2] == 1 and wd.shape[1] % 64 == 0 and \
-                            wd.shape[0] % 32 == 0 and wd.shape[0] <= 2048 and g_short.shape[1] == wd.shape[0] and \
-                            wd.shape[1] <= _DS_LINEAR["max_cin"]:
+                    if fused_ds is not None and ctx.needs_input_grad[0] and _lin_ds_static_ok(wd, ds_stride, x) and \
+                            g_short.shape[1] == wd.shape[0]:
                         # the projection shortcut's BatchNorm by linearity as well (yd = x_s Wd^T with
                         # x_s the input at the pixels the strided 1x1 conv visits): dyd never exists
-                        xs = x if ds_stride == 1 else x[:, :, ::2, ::2].contiguous(memory_format=_CL)
+                        xs = getattr(ctx, "lin_xs", None)
+                        if xs is None:
+                            xs = x if ds_stride == 1 else x[:, :, ::2, ::2].contiguous(memory_format=_CL)
                         coef_d, dgd, dbd = _unit_coef(g_short, yd, gd, bd, cd, fused_ds)
                         pre = _side_prewait(g_short.device)
                         addend, _ = _bn3_linear_dgrad(g_short, xs, wd, coef_d, None, None)
                         sub2 = ds_stride == 2
-                        dwd = _bn3_linear_wgrad(g_short, xs, wd, coef_d, cd.data_ptr(), prewaited=pre)
+                        dwd = _bn3_linear_wgrad(g_short, xs, wd, coef_d, cd, prewaited=pre,
+                                                pre=getattr(ctx, "lin_pre_ds", None))
                         put(units, dwd, dgd, dbd)
                     else:
                         dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False,
