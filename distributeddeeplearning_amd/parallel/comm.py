@@ -19,6 +19,7 @@ import hashlib
 import hmac
 import itertools
 import os
+import io
 import pickle
 
 import torch
@@ -150,6 +151,29 @@ class _HostWork(Work):
 
     def is_completed(self):
         return self.done or self.comm.lib.ddl_eng_poll(ctypes.c_longlong(self.handle)) >= 2
+
+
+class _PlainUnpickler(pickle.Unpickler):
+    """Unpickler for control-plane objects that arrive WITHOUT the job token's authentication: builds
+    containers, numbers, strings, bytes and torch dtypes / sizes only, so a blob written by a foreign
+    process cannot name a callable (what ``hvd.broadcast_object`` / ``allgather_object`` carry in
+    this framework - resume epochs, metric lists, the optimizer-state skeleton - is plain data)."""
+
+    _BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "str", "int", "float", "bool", "bytes",
+                 "bytearray", "complex", "slice", "range"}
+
+    def find_class(self, module, name):
+        if module == "builtins" and name in self._BUILTINS:
+            return getattr(__import__("builtins"), name)
+        if module == "collections" and name == "OrderedDict":
+            import collections
+
+            return collections.OrderedDict
+        if module == "torch" and (name == "Size" or isinstance(getattr(torch, name, None), torch.dtype)):
+            return getattr(torch, name)
+        raise CommError("control-plane object refused: it references %s.%s and the job has no DDL_JOB_TOKEN "
+                        "to authenticate it (launch with ddlrun, export DDL_JOB_TOKEN on every rank, or "
+                        "set DDL_TRUST_CONTROL_PLANE=1)" % (module, name))
 
 
 class _DeviceWork(Work):
@@ -447,7 +471,12 @@ class NativeComm:
         n = self.lib.ddl_eng_store_get(key.encode(), int(self.timeout_s * 1000))
         if n < 0:
             raise CommError("store get(%s) timed out" % key)
-        return pickle.loads(self._unseal(ctypes.string_at(self.lib.ddl_eng_store_data(), n)))
+        data = ctypes.string_at(self.lib.ddl_eng_store_data(), n)
+        blob = self._unseal(data)
+        if data[:1] == b"\x01" or os.environ.get("DDL_TRUST_CONTROL_PLANE") == "1":
+            return pickle.loads(blob)          # authenticated with the job token (or explicitly trusted)
+        # no job token (e.g. launched by torchrun): only plain data may come out of the store
+        return _PlainUnpickler(io.BytesIO(blob)).load()
 
     def _ack(self, key, readers, keys):
         """The last of ``readers`` readers deletes ``keys`` (the store does not grow with the job)."""

@@ -142,3 +142,29 @@ def test_engine_stress_under_thread_sanitizer(args, expect):
     assert "ThreadSanitizer" not in proc.stdout, proc.stdout[-4000:]
     assert proc.returncode == 0, proc.stdout[-4000:]
     assert expect in proc.stdout and "[stress] PASS" in proc.stdout
+
+
+def test_unauthenticated_control_plane_objects_are_plain_data_only():
+    """Without DDL_JOB_TOKEN (a torchrun launch) the store is unpickled with a restricted
+    unpickler: containers / numbers / strings / dtypes pass, anything naming a callable is refused."""
+    import io
+    import pickle
+
+    import torch
+
+    from distributeddeeplearning_amd.parallel.comm import CommError, _PlainUnpickler
+
+    obj = {"epoch": 7, "metrics": [0.5, 1.0], "state": ("__tensor__", 0, (3, 4), "torch.float32"),
+           "dtype": torch.bfloat16, "shape": torch.Size([2, 3]), "b": b"xy", "none": None}
+    assert _PlainUnpickler(io.BytesIO(pickle.dumps(obj))).load() == obj
+
+    class Evil:
+        def __reduce__(self):
+            import os
+
+            return (os.system, ("echo pwned",))
+
+    with pytest.raises(CommError):
+        _PlainUnpickler(io.BytesIO(pickle.dumps(Evil()))).load()
+    with pytest.raises(CommError):
+        _PlainUnpickler(io.BytesIO(pickle.dumps(torch.ones(2)))).load()   # tensors travel on the data plane
