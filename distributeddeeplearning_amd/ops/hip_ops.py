@@ -586,7 +586,7 @@ def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True, part
 # allocation or a view) is 3-5 us of host time, ~30 of them per layer and step, and the host has
 # to keep ahead of ~50 us kernels in the late layers (profiles/r1_notes.md).
 def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentum, eps, relu,
-              apply=True, res_coeffs=None, bits=None):
+              apply=True, res_coeffs=None, bits=None, keep=None):
     """Training-mode conv -> BatchNorm(+residual)(+ReLU).  Returns (y, z, coeffs[4, C]).
     ``apply=False`` stops after the statistics (z is None): the caller folds this BatchNorm into
     a later kernel.  ``res_coeffs``: coefficient block of such a deferred BatchNorm whose raw conv
@@ -610,6 +610,8 @@ def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentu
     cb = coeffs.data_ptr()
     K.bn_fwd_finalize(st, T, Kc, M, 128, gamma, beta, rmean, rvar, momentum, eps,
                       cb, cb + 4 * Kc, cb + 8 * Kc, cb + 12 * Kc, work=wk)
+    if keep is not None:   # launched on another stream: the caller holds the scratch until the streams are ordered
+        keep.append(tmp)
     if not apply:
         return y, None, coeffs
     z = torch.empty_like(y)
@@ -1138,6 +1140,20 @@ def batchnorm_act(x, gamma, beta, running_mean, running_var, training, momentum,
 # ----------------------------------------------------------------------------------------------
 # fused residual blocks: one autograd node per block, hand-scheduled backward
 # ----------------------------------------------------------------------------------------------
+_DS_FWD_SIDE = {"on": _os.environ.get("DDL_DS_FWD_SIDE", "1") != "0",
+                "max_hw": int(_os.environ.get("DDL_DS_FWD_SIDE_MAX_HW", "1000000"))}
+
+
+def _ds_forward_stream(x):
+    """Raw handle of the stream the projection shortcut of a block runs on in the forward pass, or
+    None for the current stream (no second stream in use, graph capture, DDL_DS_FWD_SIDE=0)."""
+    if not (_DS_FWD_SIDE["on"] and _SIDE["on"] and _SIDE_LEAN and x.is_cuda) or x.shape[2] * x.shape[3] > _DS_FWD_SIDE["max_hw"]:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    return _side_stream(x.device).cuda_stream
+
+
 class ResidualBlockFn(Function):
     """A whole bottleneck (3 conv-BN pairs) or basic block (2 pairs) plus optional projection
     shortcut as ONE autograd node (``HorovodTF/src/resnet_model.py:112-204``).
@@ -1163,14 +1179,25 @@ class ResidualBlockFn(Function):
         saved_y, saved_z, saved_c = [], [], []
         shortcut = x
         yd = cd = None
+        ds_raw = None
         if has_ds:
             wd, gd, bd, rmd, rvd = groups[units]
             if training:
                 # the projection's BatchNorm is applied inside the last unit's residual add: its
                 # normalised output is never materialised (one write + one read of the block's
                 # widest tensor less)
-                yd, _, cd = _unit_fwd(x, wd, ds_stride, 0, gd, bd, None, rmd, rvd, momentum,
-                                      eps, False, apply=False)
+                ds_raw = _ds_forward_stream(x)
+                if ds_raw is None:
+                    yd, _, cd = _unit_fwd(x, wd, ds_stride, 0, gd, bd, None, rmd, rvd, momentum,
+                                          eps, False, apply=False)
+                else:
+                    # the projection only meets the main path at the block's final residual add: it
+                    # runs on the (idle in forward) weight-gradient stream next to conv1 .. bn2
+                    K.stream_wait_stream(ds_raw, K._raw_stream(), _SIDE["event"])
+                    ds_keep = []    # scratch of the side-stream launches: alive until the main stream has waited
+                    with K.launch_on(ds_raw):
+                        yd, _, cd = _unit_fwd(x, wd, ds_stride, 0, gd, bd, None, rmd, rvd, momentum,
+                                              eps, False, apply=False, keep=ds_keep)
                 shortcut = yd
             else:
                 yd, st = _conv_fwd(x, wd, ds_stride, 0, training)
@@ -1196,6 +1223,8 @@ class ResidualBlockFn(Function):
                     zbits = torch.empty(cur.shape[0] * Ho * Wo * w.shape[0] // 8, dtype=torch.uint8,
                                         device=cur.device)
                     zbits_out = zbits
+                if last and ds_raw is not None:   # the residual add reads the projection's output
+                    K.stream_wait_stream(K._raw_stream(), ds_raw, _SIDE["event"])
                 y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, shortcut if last else None,
                                     rm, rv, momentum, eps, True,
                                     res_coeffs=cd if (last and has_ds) else None, bits=zbits)

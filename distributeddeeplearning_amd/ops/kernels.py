@@ -70,9 +70,33 @@ def _fn(name, sig):
     return f
 
 
+_STREAM_OVERRIDE = [None]   # raw HIP stream that replaces "the current stream" for every launcher (see launch_on)
+
+
 def _raw_stream():
     """Raw handle of the current stream of the current device (an int)."""
+    o = _STREAM_OVERRIDE[0]
+    if o is not None:
+        return o
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class launch_on:
+    """Every launcher called inside the block queues on raw stream ``raw`` instead of torch's current
+    stream, while tensors keep being allocated from the current stream's pool (the caller orders
+    the two streams with events; no allocator bookkeeping per tensor)."""
+
+    def __init__(self, raw):
+        self.raw = raw
+
+    def __enter__(self):
+        self.prev = _STREAM_OVERRIDE[0]
+        _STREAM_OVERRIDE[0] = self.raw
+        return self
+
+    def __exit__(self, *exc):
+        _STREAM_OVERRIDE[0] = self.prev
+        return False
 
 
 def _p(t):
