@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import threading
 import os
 
 import torch
@@ -70,32 +71,36 @@ def _fn(name, sig):
     return f
 
 
-_STREAM_OVERRIDE = [None]   # raw HIP stream that replaces "the current stream" for every launcher (see launch_on)
+class _StreamOverride(threading.local):
+    raw = None   # raw HIP stream that replaces "the current stream" for this thread's launchers (see launch_on)
+
+
+_STREAM_OVERRIDE = _StreamOverride()
 
 
 def _raw_stream():
     """Raw handle of the current stream of the current device (an int)."""
-    o = _STREAM_OVERRIDE[0]
+    o = _STREAM_OVERRIDE.raw
     if o is not None:
         return o
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 class launch_on:
-    """Every launcher called inside the block queues on raw stream ``raw`` instead of torch's current
-    stream, while tensors keep being allocated from the current stream's pool (the caller orders
+    """Every launcher this thread calls inside the block queues on raw stream ``raw`` instead of torch's
+    current stream, while tensors keep being allocated from the current stream's pool (the caller orders
     the two streams with events; no allocator bookkeeping per tensor)."""
 
     def __init__(self, raw):
         self.raw = raw
 
     def __enter__(self):
-        self.prev = _STREAM_OVERRIDE[0]
-        _STREAM_OVERRIDE[0] = self.raw
+        self.prev = _STREAM_OVERRIDE.raw
+        _STREAM_OVERRIDE.raw = self.raw
         return self
 
     def __exit__(self, *exc):
-        _STREAM_OVERRIDE[0] = self.prev
+        _STREAM_OVERRIDE.raw = self.prev
         return False
 
 
