@@ -210,3 +210,30 @@ def test_numa_affinity_helpers(tmp_path, monkeypatch):
     (dev / "numa_node").write_text("1\n")
     (node / "cpulist").write_text("100000-100003")
     assert A.bind_to_gpu_numa(0, str(tmp_path), bdf=bdf) is None
+
+
+def test_launch_stream_override_is_scoped_and_per_thread():
+    """kernels.launch_on redirects this thread's launchers to a raw stream and restores the previous
+    target on exit, nested use included; other threads keep their own."""
+    import threading
+
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    assert K._STREAM_OVERRIDE.raw is None
+    seen = {}
+    with K.launch_on(11):
+        assert K._raw_stream() == 11
+        with K.launch_on(22):
+            assert K._raw_stream() == 22
+        assert K._raw_stream() == 11
+        t = threading.Thread(target=lambda: seen.setdefault("other", K._STREAM_OVERRIDE.raw))
+        t.start()
+        t.join()
+    assert seen["other"] is None
+    assert K._STREAM_OVERRIDE.raw is None
+    try:
+        with K.launch_on(33):
+            raise ValueError("boom")
+    except ValueError:
+        pass
+    assert K._STREAM_OVERRIDE.raw is None
