@@ -470,45 +470,78 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restri
         int wo = (int)(pix % (unsigned)Wo);
         unsigned t = pix / (unsigned)Wo;
         int ho = (int)(t % (unsigned)Ho), b = (int)(t / (unsigned)Ho);
+        // Taps outside the image are read from the clamped position, which is another tap of the
+        // same window: the duplicate never changes the maximum, and it carries the window index of
+        // the pixel it duplicates (kk), so the recorded argmax is a real tap.  Scan order keeps the
+        // first maximum among the valid taps, exactly as with explicit validity flags - which cost
+        // a mask AND/OR per tap and element and spilled scalar registers (64 v_readlane + 63
+        // v_writelane in the disassembly; the kernel is bound by vector-instruction issue).
         bf16x8 v[9];
-        bool ok[9];
+        unsigned kk[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s;
-                ok[r * 3 + s] = (hi >= 0) & (hi < H) & (wi >= 0) & (wi < W);
                 int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+                kk[r * 3 + s] = (unsigned)((hc - (ho * 2 - 1)) * 3 + (wc - (wo * 2 - 1)));
                 v[r * 3 + s] = ld8<true>(x + (((long long)b * H + hc) * W + wc) * C + cc * 8);
             }
-        float sc[8], sh[8];
-        if (BN) { load8f(scale + cc * 8, sc); load8f(shift + cc * 8, sh); }
-        float best[8];
-        unsigned char bi[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { best[e] = -3.0e38f; bi[e] = 0; }
-        bool first = true;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = bf2f(v[k][e]);
-                // BN: compare the bf16-rounded activations (ties resolve exactly as on the stored
-                // tensor of the unfused path); the ReLU is monotonic and is applied to the winner —
-                // where it changes the argmax (all taps <= 0) the gradient is masked anyway
-                if (BN) f = bf2f(f2bf(bn_affine(f, sc[e], sh[e])));
-                bool take = ok[k] & (first | (f > best[e]));
-                best[e] = take ? f : best[e];
-                bi[e] = take ? (unsigned char)k : bi[e];
-            }
-            first = first & !ok[k];
-        }
         bf16x8 o;
         u32x2 packed = {0u, 0u};
+        if (BN) {
+            // One integer maximum per tap and element finds value AND argmax: the key is the
+            // bf16-rounded activation in the high half (what the unfused path stored and compared)
+            // over 15 - tap in the low bits.  As SIGNED integers positive floats order like floats and
+            // every negative one sorts below them; among equal values the earlier tap wins (window
+            // indices grow in scan order).  A window without a positive tap yields some negative
+            // winner: its output is relu(.) = 0 either way and its gradient is masked in backward,
+            // so which tap is recorded there does not matter.  NaN keys are the largest: they propagate.
+            float sc[8], sh[8];
+            load8f(scale + cc * 8, sc); load8f(shift + cc * 8, sh);
+            int key[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            o[e] = f2bf(BN ? fmaxf(best[e], 0.f) : best[e]);
-            packed[e >> 2] |= (unsigned)bi[e] << (8 * (e & 3));
+            for (int k = 0; k < 9; ++k) {
+                const unsigned low = 15u - kk[k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x2 pr;
+                    pr[0] = f2bf(bn_affine(bf2f(v[k][2 * q]), sc[2 * q], sh[2 * q]));
+                    pr[1] = f2bf(bn_affine(bf2f(v[k][2 * q + 1]), sc[2 * q + 1], sh[2 * q + 1]));
+                    const unsigned u = __builtin_bit_cast(unsigned, pr);
+                    const int k0 = (int)((u << 16) | low), k1 = (int)((u & 0xffff0000u) | low);
+                    key[2 * q] = k == 0 ? k0 : (key[2 * q] > k0 ? key[2 * q] : k0);
+                    key[2 * q + 1] = k == 0 ? k1 : (key[2 * q + 1] > k1 ? key[2 * q + 1] : k1);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float win = __builtin_bit_cast(float, (unsigned)key[e] & 0xffff0000u);
+                o[e] = f2bf(fmaxf(win, 0.f));   // (fmaxf drops a NaN operand: keep it)
+                if (win != win) o[e] = f2bf(win);
+                packed[e >> 2] |= (15u - ((unsigned)key[e] & 15u)) << (8 * (e & 3));
+            }
+        } else {
+            float best[8];
+            unsigned bi[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { best[e] = 0.f; bi[e] = kk[0]; }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bf2f(v[k][e]);
+                    if (k == 0) { best[e] = f; continue; }   // the first valid pixel (or its duplicate) starts the scan
+                    const float prev = best[e];
+                    best[e] = fmaxf(prev, f);
+                    bi[e] = f > prev ? kk[k] : bi[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = f2bf(best[e]);
+                packed[e >> 2] |= bi[e] << (8 * (e & 3));
+            }
         }
         *reinterpret_cast<bf16x8*>(out + (i << 3)) = o;
         if (idx) *reinterpret_cast<u32x2*>(idx + (i << 3)) = packed;
@@ -520,18 +553,25 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restri
 // its stored argmax is this pixel's tap.  Rounded to bf16 like the tensor the unfused path wrote.
 __device__ __forceinline__ void pool_grad8(const bf16_t* __restrict__ dpool, const unsigned char* __restrict__ idx, int b,
                                            int hi, int wi, int cc, int cchunks, int Ho, int Wo, float (&g)[8]) {
-    const int h0 = hi >> 1, h1 = (hi + 1) >> 1, w0 = wi >> 1, w1 = (wi + 1) >> 1;
+    // Pixel (hi, wi) lies in window row h0 = hi >> 1 at tap row (hi & 1) + 1 and, when hi is odd, also
+    // in window row h0 + 1 at tap row 0 (if that row exists); the same for columns.  Window (h0, w0)
+    // always exists.  A window that does not count gets the tap code 0xff, which no argmax byte holds,
+    // and is read from the address of window (h0, w0) (all loads before the first use, no branches).
+    const int h0 = hi >> 1, w0 = wi >> 1;
+    const bool hv = (hi & 1) && (h0 + 1 < Ho), wv = (wi & 1) && (w0 + 1 < Wo);
+    const unsigned r0 = (unsigned)(hi & 1) + 1u, c0 = (unsigned)(wi & 1) + 1u;
+    const long long base = ((long long)((unsigned)(b * Ho + h0) * (unsigned)Wo + (unsigned)w0) * cchunks + cc) << 3;
+    const int dw = wv ? cchunks * 8 : 0, dh = hv ? Wo * cchunks * 8 : 0;
+    unsigned tap[4];
+    tap[0] = r0 * 3u + c0;
+    tap[1] = wv ? r0 * 3u : 0xffu;
+    tap[2] = hv ? c0 : 0xffu;
+    tap[3] = (hv && wv) ? 0u : 0xffu;
     bf16x8 d[4];
     u32x2 pk[4];
-    bool ok[4];
-    unsigned tap[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int ho = (k >> 1) ? h1 : h0, wo = (k & 1) ? w1 : w0;
-        ok[k] = (ho < Ho) & (wo < Wo) & (!(k >> 1) | (h1 != h0)) & (!(k & 1) | (w1 != w0));
-        const int hc = ho < Ho ? ho : Ho - 1, wc = wo < Wo ? wo : Wo - 1;
-        tap[k] = (unsigned)((hi - (ho * 2 - 1)) * 3 + (wi - (wo * 2 - 1)));
-        const long long o = ((((long long)b * Ho + hc) * Wo + wc) * cchunks + cc) << 3;
+        const long long o = base + ((k & 1) ? dw : 0) + ((k >> 1) ? dh : 0);
         pk[k] = *reinterpret_cast<const u32x2*>(idx + o);
         d[k] = *reinterpret_cast<const bf16x8*>(dpool + o);
     }
@@ -542,7 +582,7 @@ __device__ __forceinline__ void pool_grad8(const bf16_t* __restrict__ dpool, con
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             unsigned w = (pk[k][e >> 2] >> (8 * (e & 3))) & 0xffu;
-            g[e] += (ok[k] & (w == tap[k])) ? bf2f(d[k][e]) : 0.f;
+            g[e] += (w == tap[k]) ? bf2f(d[k][e]) : 0.f;
         }
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = bf2f(f2bf(g[e]));
