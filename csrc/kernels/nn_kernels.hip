@@ -314,14 +314,33 @@ __global__ void __launch_bounds__(256) bn_apply_fwd_kernel(const bf16_t* __restr
                                                           bf16_t* __restrict__ z, unsigned char* __restrict__ bits,
                                                           long long nchunks, int cchunks) {
     long long stride = (long long)gridDim.x * blockDim.x;
+    // RES == 2 reads four coefficient vectors per chunk: 128 bytes through the vector memory path for
+    // 32 bytes of data (3.5-5.2 TB/s against 6.3 for RES == 1, profiles/r2_pmc_training_step.md).  The
+    // block stages them in LDS once (dynamic LDS: 4 * C floats) and every thread reads its slices there.
+    extern __shared__ __attribute__((aligned(16))) float co_lds[];
+    if (RES == 2) {
+        const int C = cchunks * 8;
+        for (int t = threadIdx.x * 4; t < C; t += blockDim.x * 4) {
+            *reinterpret_cast<f32x4*>(co_lds + t) = *reinterpret_cast<const f32x4*>(scale + t);
+            *reinterpret_cast<f32x4*>(co_lds + C + t) = *reinterpret_cast<const f32x4*>(shift + t);
+            *reinterpret_cast<f32x4*>(co_lds + 2 * C + t) = *reinterpret_cast<const f32x4*>(rscale + t);
+            *reinterpret_cast<f32x4*>(co_lds + 3 * C + t) = *reinterpret_cast<const f32x4*>(rshift + t);
+        }
+        __syncthreads();
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
         int c = (int)(i % cchunks) * 8;
         bf16x8 v = ld8<NT>(y + (i << 3));
         float sc[8], sh[8], rsc[8], rsh[8];
-        load8f(scale + c, sc); load8f(shift + c, sh);
         bf16x8 r;
         if (RES) r = ld8<NT>(res + (i << 3));
-        if (RES == 2) { load8f(rscale + c, rsc); load8f(rshift + c, rsh); }
+        if (RES == 2) {
+            const int C = cchunks * 8;
+            load8f(co_lds + c, sc); load8f(co_lds + C + c, sh);
+            load8f(co_lds + 2 * C + c, rsc); load8f(co_lds + 3 * C + c, rsh);
+        } else {
+            load8f(scale + c, sc); load8f(shift + c, sh);
+        }
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -995,11 +1014,12 @@ extern "C" int ddl_bn_apply_fwd_ex2(const void* y, const void* scale, const void
     CHK((rscale == nullptr) == (rshift == nullptr) && (!rscale || res), DDL_EINVAL);
     CHK(ddl_aligned16(y) && ddl_aligned16(z) && ddl_aligned16(scale) && ddl_aligned16(shift) && (!res || ddl_aligned16(res)), DDL_EALIGN);
     CHK(!rscale || (ddl_aligned16(rscale) && ddl_aligned16(rshift)), DDL_EALIGN);
+    CHK(!rscale || C <= 4096, DDL_EINVAL);   // the two-BatchNorm variant stages 4 * C floats in LDS
     long long nchunks = M * (C >> 3);
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
     const bool nt = M * C * 2 >= nt_threshold_bytes();
     const int rmode = !res ? 0 : (rscale ? 2 : 1);
-#define L2(R, S, N) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S, N>), grid, block, 0, stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (const float*)rscale, (const float*)rshift, (bf16_t*)z, (unsigned char*)bits, nchunks, C >> 3)
+#define L2(R, S, N) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S, N>), grid, block, (S == 2 ? 16 * (size_t)C : 0), stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (const float*)rscale, (const float*)rshift, (bf16_t*)z, (unsigned char*)bits, nchunks, C >> 3)
 #define L(R, S) do { if (nt) L2(R, S, true); else L2(R, S, false); } while (0)
 #define LR(R) do { if (rmode == 2) L(R, 2); else if (rmode == 1) L(R, 1); else L(R, 0); } while (0)
     if (relu) LR(true); else LR(false);
