@@ -444,6 +444,15 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
                                                           long long nchunks, int cchunks) {
     const int C = cchunks * 8;
     long long stride = (long long)gridDim.x * blockDim.x;
+    // coefficients through LDS (3 * C floats, 5 * C with the recomputed mask): see bn_apply_fwd_kernel
+    extern __shared__ __attribute__((aligned(16))) float co_lds[];
+    for (int t = threadIdx.x * 4; t < 3 * C; t += blockDim.x * 4)
+        *reinterpret_cast<f32x4*>(co_lds + t) = *reinterpret_cast<const f32x4*>(coef + t);
+    if (MASK == 2) {
+        for (int t = threadIdx.x * 4; t < 2 * C; t += blockDim.x * 4)
+            *reinterpret_cast<f32x4*>(co_lds + 3 * C + t) = *reinterpret_cast<const f32x4*>(fcoef + t);
+    }
+    __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
         int c = (int)(i % cchunks) * 8;
         bf16x8 d = ld8<NT>(dz + (i << 3));
@@ -451,8 +460,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
         bf16x8 zv;
         if (MASK == 1) zv = ld8<NT>(z + (i << 3));
         float ca[8], cb[8], c0[8], sc[8], sh[8];
-        load8f(coef + c, ca); load8f(coef + C + c, cb); load8f(coef + 2 * C + c, c0);
-        if (MASK == 2) { load8f(fcoef + c, sc); load8f(fcoef + C + c, sh); }
+        load8f(co_lds + c, ca); load8f(co_lds + C + c, cb); load8f(co_lds + 2 * C + c, c0);
+        if (MASK == 2) { load8f(co_lds + 3 * C + c, sc); load8f(co_lds + 4 * C + c, sh); }
         bf16x8 o, go;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1095,12 +1104,13 @@ extern "C" int ddl_bn_bwd_apply(const void* dz, const void* y, const void* z, co
                                 void* gout, long long M, int C, int mask, hipStream_t stream) {
     CHK(dz && y && coef && dy && M > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
     CHK(mask == 0 || (mask == 1 && z) || (mask == 2 && fcoef), DDL_EINVAL);
+    CHK(C <= 3072, DDL_EINVAL);   // coefficients are staged in LDS: up to 5 * C floats
     CHK(ddl_aligned16(dz) && ddl_aligned16(y) && ddl_aligned16(dy) && ddl_aligned16(coef) && (!z || ddl_aligned16(z)) &&
         (!gout || ddl_aligned16(gout)) && (!fcoef || ddl_aligned16(fcoef)), DDL_EALIGN);
     long long nchunks = M * (C >> 3);
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
     const bool nt = M * C * 2 >= nt_threshold_bytes();
-#define L2(MK, G, N) hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, G, N>), grid, block, 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
+#define L2(MK, G, N) hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, G, N>), grid, block, (MK == 2 ? 20 : 12) * (size_t)C, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
 #define L(MK, G) do { if (nt) L2(MK, G, true); else L2(MK, G, false); } while (0)
     if (mask == 1) { if (gout) L(1, true); else L(1, false); }
     else if (mask == 2) { if (gout) L(2, true); else L(2, false); }
