@@ -646,42 +646,86 @@ __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const bf16_t* __r
                                                               const bf16_t* __restrict__ y, const float* __restrict__ fcoef,
                                                               const float* __restrict__ coef, float* __restrict__ partial,
                                                               bf16_t* __restrict__ dy, int B, int H, int W, int C, int Ho, int Wo,
-                                                              long long rows_per_block) {
+                                                              long long patches_per_block) {
+    // A thread owns a 2x2 pixel patch (rows 2a, 2a+1, columns 2q, 2q+1) of 8 channels.  The patch
+    // touches exactly four pool windows - (a, q) holds all four pixels, (a, q+1) the odd column,
+    // (a+1, q) the odd row, (a+1, q+1) the odd/odd pixel - so 4 + 4 window loads serve 4 pixels.
+    // (One pixel per thread read four windows each, 16 + 16 loads per patch, most of them clamped
+    // duplicates: the kernel sat on the vector memory path at 4.1 TB/s.)
     __shared__ float red[2][2048];
-    const int cchunks = C >> 3, rlanes = 256 / cchunks;
-    const int cc = threadIdx.x % cchunks, rl = threadIdx.x / cchunks;
-    const long long M = (long long)B * H * W;
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
-    long long r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    const int cchunks = C >> 3, planes = 256 / cchunks;
+    const int cc = threadIdx.x % cchunks, pl = threadIdx.x / cchunks;
+    const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+    const long long NP = (long long)B * PH * PW;
+    const long long p0 = (long long)blockIdx.x * patches_per_block;
+    long long p1 = p0 + patches_per_block;
+    if (p1 > NP) p1 = NP;
     float s1[8], s2[8], sc[8], sh[8], ca[8], cb[8], c0[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     load8f(fcoef + cc * 8, sc); load8f(fcoef + C + cc * 8, sh);
     if (APPLY) { load8f(coef + cc * 8, ca); load8f(coef + C + cc * 8, cb); load8f(coef + 2 * C + cc * 8, c0); }
-    // pixel coordinates of the first row, then stepped by `rlanes` pixels per trip
-    int wi, hi, b;
+    // patch coordinates of the first patch, then stepped by `planes` patches per trip
+    int q, a, b;
     {
-        const unsigned ru = (unsigned)(r0 + rl);
-        wi = (int)(ru % (unsigned)W);
-        const unsigned t = ru / (unsigned)W;
-        hi = (int)(t % (unsigned)H); b = (int)(t / (unsigned)H);
+        const unsigned pu = (unsigned)(p0 + pl);
+        q = (int)(pu % (unsigned)PW);
+        const unsigned t = pu / (unsigned)PW;
+        a = (int)(t % (unsigned)PH); b = (int)(t / (unsigned)PH);
     }
-    for (long long r = r0 + rl; r < r1; r += rlanes) {
-        bf16x8 yv = ld8<true>(y + r * C + cc * 8);
-        float g[8];
-        pool_grad8(dpool, idx, b, hi, wi, cc, cchunks, Ho, Wo, g);
-        wi += rlanes;
-        while (wi >= W) { wi -= W; if (++hi == H) { hi = 0; ++b; } }
-        bf16x8 o;
+    for (long long p = p0 + pl; p < p1; p += planes) {
+        const bool rv = 2 * a + 1 < H, cv = 2 * q + 1 < W;        // the patch's odd row / column are inside the image
+        const bool wv = q + 1 < Wo, hv = a + 1 < Ho;               // windows to the right / below exist
+        // windows (a, q), (a, q+1), (a+1, q), (a+1, q+1); a window that does not exist is read at (a, q) and never matches
+        const long long wbase = ((long long)((unsigned)(b * Ho + a) * (unsigned)Wo + (unsigned)q) * cchunks + cc) << 3;
+        const int dwo = wv ? cchunks * 8 : 0, dho = hv ? Wo * cchunks * 8 : 0;
+        bf16x8 d[4];
+        u32x2 pk[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float yf = bf2f(yv[e]);
-            float ge = bn_affine(yf, sc[e], sh[e]) > 0.f ? g[e] : 0.f;
-            if (APPLY) o[e] = f2bf(ca[e] * ge + cb[e] * yf + c0[e]);
-            else { s1[e] += ge; s2[e] += ge * yf; }
+        for (int k = 0; k < 4; ++k) {
+            const long long o = wbase + ((k & 1) ? dwo : 0) + ((k >> 1) ? dho : 0);
+            pk[k] = *reinterpret_cast<const u32x2*>(idx + o);
+            d[k] = *reinterpret_cast<const bf16x8*>(dpool + o);
         }
-        if (APPLY) st8<true>(dy + r * C + cc * 8, o);
+        // the four pixels (missing ones are read at the patch's first pixel and dropped)
+        const long long ybase = (((long long)(b * H + 2 * a) * W + 2 * q) * C) + cc * 8;
+        const long long ydw = cv ? C : 0, ydh = rv ? (long long)W * C : 0;
+        bf16x8 yv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = ld8<true>(y + ybase + ((j & 1) ? ydw : 0) + ((j >> 1) ? ydh : 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dh = j >> 1, dwp = j & 1;
+            const bool live = (!dh | rv) & (!dwp | cv);            // uniform per thread and pixel
+            // tap code of this pixel in each window that holds it (0xff: the window does not hold it / does not exist)
+            unsigned tap[4];
+            tap[0] = (unsigned)((dh + 1) * 3 + (dwp + 1));
+            tap[1] = (dwp && wv) ? (unsigned)((dh + 1) * 3) : 0xffu;
+            tap[2] = (dh && hv) ? (unsigned)(dwp + 1) : 0xffu;
+            tap[3] = (dh && dwp && hv && wv) ? 0u : 0xffu;
+            float g[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    unsigned w = (pk[k][e >> 2] >> (8 * (e & 3))) & 0xffu;
+                    g[e] += (w == tap[k]) ? bf2f(d[k][e]) : 0.f;
+                }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gr = bf2f(f2bf(g[e]));   // rounded like the tensor the unfused path wrote
+                const float yf = bf2f(yv[j][e]);
+                const float ge = (live && bn_affine(yf, sc[e], sh[e]) > 0.f) ? gr : 0.f;
+                if (APPLY) o[e] = f2bf(ca[e] * ge + cb[e] * yf + c0[e]);
+                else { s1[e] += ge; s2[e] += ge * yf; }
+            }
+            if (APPLY && live) st8<true>(dy + ybase + (dwp ? ydw : 0) + (dh ? ydh : 0), o);
+        }
+        q += planes;
+        while (q >= PW) { q -= PW; if (++a == PH) { a = 0; ++b; } }
     }
     if (!APPLY) {
 #pragma unroll
@@ -690,7 +734,7 @@ __global__ void __launch_bounds__(256) stem_pool_bn_bwd_kernel(const bf16_t* __r
         for (int t = threadIdx.x; t < 2 * C; t += 256) {
             int which = t / C, c = t - which * C;
             float acc = 0.f;
-            for (int l = 0; l < rlanes; ++l) acc += red[which][(l * cchunks + (c >> 3)) * 8 + (c & 7)];
+            for (int l = 0; l < planes; ++l) acc += red[which][(l * cchunks + (c >> 3)) * 8 + (c & 7)];
             partial[((long long)blockIdx.x * 2 + which) * C + c] = acc;
         }
     }
@@ -1157,8 +1201,9 @@ extern "C" int ddl_stem_pool_bn_bwd(const void* dpool, const void* idx, const vo
         (!coef || ddl_aligned16(coef)) && (!dy || ddl_aligned16(dy)), DDL_EALIGN);
     int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     long long M = (long long)B * H * W;
-    CHK(M < (1LL << 32), DDL_EINVAL);
-    long long rpb = (M + G - 1) / G;
+    CHK(M < (1LL << 31), DDL_EINVAL);
+    const long long NP = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);   // 2x2 pixel patches
+    long long rpb = (NP + G - 1) / G;
     if (apply) hipLaunchKernelGGL(stem_pool_bn_bwd_kernel<true>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dpool,
                                   (const unsigned char*)idx, (const bf16_t*)y, (const float*)fcoef, (const float*)coef,
                                   (float*)nullptr, (bf16_t*)dy, B, H, W, C, Ho, Wo, rpb);

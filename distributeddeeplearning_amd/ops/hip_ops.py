@@ -1048,7 +1048,7 @@ class StemFn(Function):
             dg, db = dgb[0], dgb[1]
         dy = torch.empty_like(y)
         K.stem_pool_bn_bwd(dout, idx, y, fco, coef, None, dy, B, Ho, Wo, Kc,
-                           min(max(M // 64, 1), 16384), True)
+                           min(max(M // 64, 1), _STEM_APPLY_BLOCKS), True)
         if direct:
             _notify(gamma)
             _notify(beta)
@@ -1065,6 +1065,7 @@ _PROBE_SKIP_WIDE_APPLY = _os.environ.get("DDL_PROBE_SKIP_WIDE_APPLY", "0") == "1
 
 # blocks of the stem's fused reduce pass (one [2][C] partial row each)
 _STEM_REDUCE_BLOCKS = int(_os.environ.get("DDL_STEM_REDUCE_BLOCKS", "4096"))
+_STEM_APPLY_BLOCKS = int(_os.environ.get("DDL_STEM_APPLY_BLOCKS", "4096"))   # blocks of the apply pass (2048-8192 measured equal, 16384+ slower)
 
 
 def stem_supported(weight, stride, padding):

@@ -686,13 +686,19 @@ def test_fused_stem_matches_composition():
     """StemFn (conv 7x7/2 -> BN -> ReLU -> maxpool in one node, activation never written) against
     the same computation composed from the separate HIP ops."""
     hip = _hip()
+    for (B, H, W) in [(5, 64, 96), (3, 70, 90), (2, 66, 58)]:   # conv output 32x48, 35x45 (odd: partial 2x2 patches), 33x29
+        _fused_stem_case(hip, B, H, W)
+
+
+def _fused_stem_case(hip, B, H, W):
     hip.reset_caches()
-    B, H, W = 5, 64, 96
     x = torch.rand((B, 3, H, W), device=DEV).to(BF).contiguous(memory_format=CL)
     w0 = (torch.randn((64, 3, 7, 7), device=DEV) / math.sqrt(147)).to(BF).contiguous(memory_format=CL)
     g0 = torch.rand(64, device=DEV) + 0.5
     b0 = torch.randn(64, device=DEV) * 0.2
-    gout = rand_nhwc(B, 64, 16, 24, seed=51)
+    Hc, Wc = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = (Hc + 2 - 3) // 2 + 1, (Wc + 2 - 3) // 2 + 1
+    gout = rand_nhwc(B, 64, Hp, Wp, seed=51)
 
     def run(fused):
         w = w0.clone().requires_grad_(True)
@@ -708,7 +714,7 @@ def test_fused_stem_matches_composition():
         return out.detach(), w.grad, gamma.grad, beta.grad, rm, rv
 
     a, b = run(False), run(True)
-    assert a[0].shape == (B, 64, 16, 24)
+    assert a[0].shape == (B, 64, Hp, Wp)
     assert torch.equal(a[0], b[0])
     for i in (1, 2, 3):
         assert rms_relerr(b[i], a[i]) < 1e-2, i
