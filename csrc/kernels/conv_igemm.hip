@@ -596,8 +596,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
                 }
             }
             if (EPI == 1) {
+                // (rows and columns past the edge are exact zeros here: their operand rows were
+                // zero-filled by the buffer range check and the forward launch has no bias and no addend)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float f = bf2f(v[e]) * live; s1[e] += f; s2[e] += f * f; }
+                for (int e = 0; e < 8; ++e) { float f = bf2f(v[e]); s1[e] += f; s2[e] += f * f; }
             }
             if (ok[b]) *reinterpret_cast<bf16x8*>(p.y + off[b]) = v;
         }
