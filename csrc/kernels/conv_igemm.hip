@@ -591,7 +591,8 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
                     float yf = bf2f(yv[b][e]);
                     bool on = bn_affine(yf, fsc[e], fsh[e]) > 0.f;
                     v[e] = on ? v[e] : f2bf(0.f);
-                    float g = bf2f(v[e]) * live;
+                    float g = bf2f(v[e]);
+                    if (DUAL) g *= live;   // (without the bias of the two-segment form rows past the edge are exact zeros)
                     s1[e] += g; s2[e] += g * yf;
                 }
             }
