@@ -96,7 +96,11 @@ __device__ __forceinline__ int wt_swz(int row) {
 }
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
-template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS, bool WT = false, bool DUAL = false>
+// LEAN (EPI 4 only): the ReLU mask arrives as bits and there is no second BatchNorm table - the common
+// launch of the training step.  As compile-time facts they free the registers of the two alternatives
+// (a bf16 mask tile, the second pre-BatchNorm tile, a third sum): 152 -> 128 VGPRs or fewer, i.e. 4
+// workgroups per CU instead of 3 for a kernel that is sensitive to exactly that (profiles/r2_notes.md).
+template <int BM, int BN, int BK, int EPI, bool ADDEND, bool GLDS, bool WT = false, bool DUAL = false, bool LEAN = false>
 __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WAVES : 2) conv_igemm_kernel(const IGemmParams p) {
     static_assert(!DUAL || (GLDS && !WT && !ADDEND), "the two-segment reduction exists for LDS-DMA plain GEMMs");
     static_assert(BM % 128 == 0, "statistics rows are per 128 output rows");
@@ -458,8 +462,9 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
     float s1[8], s2[8], s3[8], fsc[8], fsh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; fsc[e] = 0.f; fsh[e] = 0.f; }
-    const bool y2on = EPI == 4 && p.ep_y2 != nullptr;  // uniform
-    const bool maskbits = (EPI == 3 || EPI == 4) && p.ep_maskbits != nullptr;  // uniform
+    static_assert(!LEAN || EPI == 4, "LEAN is a specialisation of the block-input-gradient epilogue");
+    const bool y2on = !LEAN && EPI == 4 && p.ep_y2 != nullptr;  // uniform
+    const bool maskbits = LEAN || ((EPI == 3 || EPI == 4) && p.ep_maskbits != nullptr);  // uniform
     if (EPI == 2 && n < p.N) { load8f(p.ep_fcoef + n, fsc); load8f(p.ep_fcoef + p.N + n, fsh); }
     // Rows are handled in batches: all global reads of a batch (shortcut gradient, ReLU mask, BN
     // input) are issued back to back with clamped addresses — no branch and no wait between them —
@@ -629,8 +634,10 @@ int launch_cfg2(const IGemmParams& p, hipStream_t stream) {
     const bool mask = p.ep_mask || p.ep_maskbits;
     if (p.stats && p.addend && !(p.ep_y && mask)) return DDL_EINVAL;
 #define DDL_LAUNCH(E, A) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, E, A, GLDS, WT>), grid, block, extra_lds, stream, p)
-    if (p.ep_y && mask && p.addend) DDL_LAUNCH(4, true);
-    else if (p.ep_y && mask) DDL_LAUNCH(4, false);
+    const bool lean = p.ep_maskbits && !p.ep_y2;
+#define DDL_LAUNCH_LEAN(A) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, A, GLDS, WT, false, true>), grid, block, extra_lds, stream, p)
+    if (p.ep_y && mask && p.addend) { if (lean) DDL_LAUNCH_LEAN(true); else DDL_LAUNCH(4, true); }
+    else if (p.ep_y && mask) { if (lean) DDL_LAUNCH_LEAN(false); else DDL_LAUNCH(4, false); }
     else if (p.ep_y) DDL_LAUNCH(2, false);
     else if (mask && p.addend) DDL_LAUNCH(3, true);
     else if (mask) DDL_LAUNCH(3, false);
@@ -641,6 +648,7 @@ int launch_cfg2(const IGemmParams& p, hipStream_t stream) {
     else if (p.addend) DDL_LAUNCH(0, true);
     else DDL_LAUNCH(0, false);
 #undef DDL_LAUNCH
+#undef DDL_LAUNCH_LEAN
     return ddl_launch_status();
 }
 
