@@ -389,13 +389,17 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
     // 1x1 GEMMs with >= 128 channels on both sides with 64 rows per tile (half the barriers: c1
     // 100 -> 84 us, d1 70 -> 63, b5 57 -> 51; with 32 rows LDS-DMA loses 5-15 % there, with 64 rows the
     // 3x3 filters lose 10-15 % to the 64 KB of LDS).  The bandwidth-bound 64-channel layers keep the
-    // register-staged loop.  DDL_WGRAD_GLDS=0|1 and DDL_WGRAD_BK=32|64 force.
+    // register-staged loop.  IN THE TRAINING STEP the 1x1 GEMMs stay register-staged as well: their
+    // LDS-DMA form wins in isolation but its 64 KB per workgroup (two resident per CU) leaves no room
+    // for the dependent chain's conv workgroups next to it - 18.29 / 18.29 ms per step with it, 18.21 /
+    // 18.19 without (profiles/r2_notes.md section 22).  DDL_WGRAD_GLDS=0|1|2 (2: the isolated optimum)
+    // and DDL_WGRAD_BK=32|64 force.
     static const int glds_env = getenv("DDL_WGRAD_GLDS") ? atoi(getenv("DDL_WGRAD_GLDS")) : -1;  // tuning knob
     static const int bk_env = getenv("DDL_WGRAD_BK") ? atoi(getenv("DDL_WGRAD_BK")) : 0;         // tuning knob
     constexpr bool CAN = (BMw == 64 || BMw == 128) && (BNw == 64 || BNw == 128);
     if constexpr (CAN) {
         const bool one = p.R * p.S == 1;
-        const bool glds = glds_env > 0 || (glds_env < 0 && (!one || (p.K >= 128 && p.C >= 128)));
+        const bool glds = glds_env == 2 ? (!one || (p.K >= 128 && p.C >= 128)) : (glds_env > 0 || (glds_env < 0 && !one));   // 2: also the wide 1x1 GEMMs (the isolated optimum)
         const bool bk64 = glds && (bk_env == 64 || (bk_env == 0 && one));
         if (bk64) {
             if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true, true, 64>), grid, block, 0, stream, p);
