@@ -140,6 +140,38 @@ def test_batchnorm_act(shape, relu, res):
         assert rms_relerr(r.grad, rr.grad) < 1e-2
 
 
+@pytest.mark.parametrize("T,C", [(37, 64), (512, 256), (513, 128), (1568, 128), (1568, 520), (2048, 64), (2049, 64),
+                                 (6272, 64)])
+def test_bn_fwd_finalize_table_lengths(T, C):
+    """Both routes of the statistics finalize (one launch up to 512 tiles, fold + finalize above)
+    against an fp64 reduction of the same partial table."""
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    g = torch.Generator(device="cpu").manual_seed(T * 131 + C)
+    rows = 128
+    M = (T - 1) * rows + 77
+    s1 = torch.randn((T, C), generator=g) * 4.0 + 64.0            # per-tile sums with a common offset
+    s2 = s1 * s1 / rows + torch.rand((T, C), generator=g) * 50.0   # per-tile sums of squares (>= s1^2 / rows)
+    partial = torch.stack([s1, s2], dim=1).contiguous().to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = torch.randn(C, generator=g).to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, inv, sc, sh = (torch.empty(C, device=DEV) for _ in range(4))
+    K.bn_fwd_finalize(partial, T, C, M, rows, gamma, beta, rm, rv, 0.1, 1e-5, mean, inv, sc, sh)
+    torch.cuda.synchronize()
+    p64 = partial.double().cpu()
+    S1, S2 = p64[:, 0].sum(0), p64[:, 1].sum(0)
+    mu = S1 / M
+    var = (S2 / M - mu * mu).clamp_min(0)
+    inv_ref = 1.0 / torch.sqrt(var + 1e-5)
+    assert torch.allclose(mean.cpu().double(), mu, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(inv.cpu().double(), inv_ref, rtol=2e-5, atol=0)
+    assert torch.allclose(sc.cpu().double(), gamma.cpu().double() * inv_ref, rtol=2e-5, atol=0)
+    assert torch.allclose(sh.cpu().double(), beta.cpu().double() - mu * gamma.cpu().double() * inv_ref, rtol=2e-5, atol=1e-5)
+    assert torch.allclose(rm.cpu().double(), 0.1 * mu, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv.cpu().double(), 0.9 + 0.1 * var * M / (M - 1), rtol=2e-5, atol=1e-6)
+
+
 def test_bn_apply_writes_relu_bitmask():
     """``bits`` of the forward BatchNorm apply: bit e of byte i = (z[8i + e] > 0)."""
     from distributeddeeplearning_amd.ops import kernels as K
