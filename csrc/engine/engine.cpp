@@ -453,7 +453,14 @@ private:
     // Device collectives in flight: completion (-> per-collective device time), stall warning, and
     // the hard timeout.  A collective that does not finish within `timeout_s` (a dead or wedged
     // peer) is aborted and every handle fails: synchronize() raises instead of hanging.
-    bool watch_bound_ = false;
+    // bound PER THREAD: harvest() runs this from Python threads as well as from the watchdog thread,
+    // and a flag shared between them left the watchdog thread without its hipSetDevice
+    static bool& thread_bound() { static thread_local bool b = false; return b; }
+    // per-collective device times are kept for stable names only (the gradient buckets, the init
+    // self-test, named user collectives): auto-named ops (`allreduce.noname.<n>`) would grow the map
+    // without bound and push the grad.* lines out of the caller's buffer
+    static bool keeps_stats(const std::string& name) { return name.find(".noname.") == std::string::npos; }
+    static constexpr size_t kMaxStats = 512;
     void watch_device() {
         if (!g_plane) return;
         std::string dead;
@@ -465,7 +472,7 @@ private:
             const bool ktmo = g_plane->kernel_timeout() != 0;
             if (ktmo && inflight_.empty()) dead = "xgmi all-reduce (a peer never arrived: spin limit reached)";
             if (inflight_.empty() && !ktmo) return;
-            if (!watch_bound_) watch_bound_ = g_plane->bind_thread();
+            if (!thread_bound()) thread_bound() = g_plane->bind_thread();
             const double now = now_us();
             for (auto it = inflight_.begin(); it != inflight_.end();) {
                 Inflight& f = it->second;
@@ -474,8 +481,8 @@ private:
                     if (q == 1 && !ktmo) {
                         f.completed = true;
                         const float ms = g_plane->elapsed_ms(f.ticket);
-                        auto& st = stats_[f.name];
-                        ++st.count; st.last_ms = ms; st.total_ms += ms;
+                        auto sit = stats_.find(f.name);
+                        if (sit != stats_.end()) { auto& st = sit->second; ++st.count; st.last_ms = ms; st.total_ms += ms; }
                         timeline_event(f.name, "DEVICE_DONE", 'i', now);
                     } else {
                         const double el = (now - f.t_launch) * 1e-6;
@@ -501,8 +508,11 @@ private:
             snprintf(why, sizeof(why), "device collective '%s' did not complete within %.1f s (in flight for %.1f s); aborting the communicator",
                      dead.c_str(), timeout_s, dead_for);
             fprintf(stderr, "[ddl engine rank %d] ERROR: %s\n", rank, why);
-            g_plane->abort(why);
+            // Python first: every waiter raises NOW.  The plane's abort (ncclCommAbort, then the
+            // diagnostic snapshot) may itself take time on a wedged device and must never stand
+            // between a dead collective and the error the job is waiting for.
             fail_all(why);
+            g_plane->abort(why);
         }
     }
 
@@ -633,9 +643,11 @@ private:
                 }
                 {
                     std::lock_guard<std::mutex> g(mu_);
-                    auto& st = stats_[op.name];
-                    st.algo = fl.ticket.algo;
-                    st.bytes = op.count * (long long)dtype_size(op.dtype);
+                    if (keeps_stats(op.name) && (stats_.count(op.name) || stats_.size() < kMaxStats)) {
+                        auto& st = stats_[op.name];
+                        st.algo = fl.ticket.algo;
+                        st.bytes = op.count * (long long)dtype_size(op.dtype);
+                    }
                     inflight_[op.handle] = fl;
                     status_[op.handle] = RUNNING;
                 }
@@ -767,7 +779,7 @@ long long ddl_eng_stats(char* buf, long long cap) {
     const long long n = (long long)t.size() < cap - 1 ? (long long)t.size() : cap - 1;
     std::memcpy(buf, t.data(), (size_t)n);
     buf[n] = 0;
-    return n;
+    return (long long)t.size();   // the REQUIRED length: a caller that sees >= cap grows its buffer and asks again
 }
 
 int ddl_eng_poll(long long handle) { return g_engine ? g_engine->poll(handle) : -1; }

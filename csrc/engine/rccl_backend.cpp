@@ -168,11 +168,16 @@ void plane_recycle(ddl::DeviceTicket* t) {
 void plane_abort(const char* why) {
     if (g.aborted.exchange(true)) return;
     fprintf(stderr, "[ddl rccl rank %d] aborting the communicator: %s\n", g.rank, why ? why : "");
-    if (ddl::xgmi::active()) fprintf(stderr, "[ddl xgmi] %s\n", ddl::xgmi::describe().c_str());
-    // ncclCommAbort stops the communicator's kernels so that a wedged collective releases the GPU
-    // and any host thread blocked in a stream/device synchronisation returns
+    // 1. release what can hold the GPU: spinning xGMI kernels see the raised word within 4096 polls,
+    //    ncclCommAbort stops the communicator's kernels - so that a wedged collective frees the device
+    //    and any host thread blocked in a stream/device synchronisation returns
+    const bool xgmi_on = ddl::xgmi::active();
+    if (xgmi_on) ddl::xgmi::raise_abort();
     if (g.comm) (void)ncclCommAbort(g.comm);
     g.comm = nullptr;
+    // 2. only then the diagnostic snapshot (bounded wait on a private stream: never the null stream,
+    //    which may itself sit behind the dead collective's `done` event)
+    if (xgmi_on) fprintf(stderr, "[ddl xgmi] %s\n", ddl::xgmi::describe().c_str());
 }
 
 int plane_kernel_timeout() { return ddl::xgmi::timeout_flag(); }

@@ -206,13 +206,42 @@ bool launch(void* buf, long long count, bool bf16, bool one_shot, float scale, h
 
 int timeout_flag() { return S.timeout_host && *(volatile unsigned*)S.timeout_host != 0 ? 1 : 0; }
 
+// host-side abort: spinning kernels see the word within 4096 polls and return (first diagnosis wins)
+void raise_abort() {
+    if (S.timeout_host && *(volatile unsigned*)S.timeout_host == 0) *(volatile unsigned*)S.timeout_host = 0x400u;
+}
+
 // what the flag page looked like when a kernel gave up: which peer never announced / finished
 std::string describe() {
     std::lock_guard<std::mutex> lk(S.mu);
     if (!S.on) return "xgmi plane off";
+    // The null stream may sit behind the very collective that hangs (torch's default stream IS the
+    // null stream and waits on `done` events): a synchronous hipMemcpy here would never return and
+    // the watchdog that calls this would never reach fail_all().  Snapshot through a private
+    // non-blocking stream into pinned memory and wait for it for at most 2 s.
     unsigned words[32] = {0};
     char buf[512];
-    if (hipMemcpy(words, S.flag_page, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess) return "flag page unreadable";
+    {
+        hipStream_t st = nullptr;
+        unsigned* pinned = nullptr;
+        hipEvent_t ev = nullptr;
+        bool got = false;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+            hipHostMalloc((void**)&pinned, sizeof(words), hipHostMallocDefault) == hipSuccess &&
+            hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess &&
+            hipMemcpyAsync(pinned, S.flag_page, sizeof(words), hipMemcpyDeviceToHost, st) == hipSuccess &&
+            hipEventRecord(ev, st) == hipSuccess) {
+            for (int i = 0; i < 2000 && !got; ++i) {
+                if (hipEventQuery(ev) == hipSuccess) got = true;
+                else usleep(1000);
+            }
+            if (got) std::memcpy(words, pinned, sizeof(words));
+        }
+        // a copy that never finished keeps its stream and buffer (leaked on purpose: the process is
+        // about to fail anyway and freeing them could block)
+        if (got) { (void)hipEventDestroy(ev); (void)hipHostFree(pinned); (void)hipStreamDestroy(st); }
+        if (!got) return "flag page unreadable within 2 s (device busy)";
+    }
     int n = snprintf(buf, sizeof(buf), "rank %d epoch %u timeout_word %u ready[", S.rank, S.epoch, S.timeout_host ? *S.timeout_host : 0u);
     for (int i = 0; i < S.size; ++i) n += snprintf(buf + n, sizeof(buf) - n, "%u ", words[i]);
     n += snprintf(buf + n, sizeof(buf) - n, "] done[");

@@ -20,6 +20,7 @@ int register_region(void* ptr, size_t bytes, std::string* err);
 bool usable(const void* buf, size_t bytes, long long count, int nranks);
 bool launch(void* buf, long long count, bool bf16, bool one_shot, float scale, hipStream_t stream, std::string* err);
 int timeout_flag();   // 1 once any launch of this process reported an expired spin
+void raise_abort();   // host-side: make every spinning kernel of this process give up (bounded by 4096 polls)
 std::string describe();  // flag-page snapshot for the watchdog's timeout report
 bool active();
 void shutdown();

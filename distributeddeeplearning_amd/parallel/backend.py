@@ -6,9 +6,16 @@ Parity target: ``hvd.init()``, ``hvd.rank()``, ``hvd.local_rank()``, ``hvd.size(
 MI355X design: one process per GPU, rendezvous from the environment (``RANK``/``WORLD_SIZE``/
 ``LOCAL_RANK``/``MASTER_ADDR``/``MASTER_PORT`` as exported by ``torch.distributed.run`` or by
 our own launcher; OpenMPI's ``OMPI_COMM_WORLD_*`` names are honoured too so an ``mpirun`` line
-from the reference notebooks still works).  The data plane is RCCL over xGMI
-(``torch.distributed`` backend ``"nccl"`` on ROCm); the CPU/gloo backend serves the GPU-less
-plumbing configuration (BASELINE.json config 1) and the tests.  No MPI anywhere.
+from the reference notebooks still works).  On GPUs the data plane is the in-tree C++ engine
+(``csrc/engine``: RCCL over xGMI called directly from its own communication thread, optionally
+the direct xGMI kernel); ``HVD_ENGINE=torch`` selects ``torch.distributed``'s process group
+instead (backend ``"nccl"`` IS RCCL on ROCm).  The CPU/gloo backend serves the GPU-less plumbing
+configuration (BASELINE.json config 1) and the tests.  No MPI anywhere.
+
+Every communicator proves itself before ``init()`` returns (``parallel/selftest.py``): a checked
+all-reduce per enabled algorithm and wire dtype, a broadcast and an all-gather, under a timeout.
+A failure ends the job with the engine's diagnosis unless ``HVD_ENGINE_FALLBACK=torch`` lets all
+ranks agree on the c10d process group - loudly (stderr, ``engine_name()``).
 """
 from __future__ import annotations
 
@@ -23,7 +30,8 @@ from ..utils.config import EngineConfig
 
 __all__ = ["init", "shutdown", "is_initialized", "rank", "size", "local_rank", "local_size",
            "cross_rank", "cross_size", "backend_name", "device", "group", "barrier",
-           "engine_config", "NotInitializedError", "supports_avg", "comm", "engine_name"]
+           "engine_config", "NotInitializedError", "supports_avg", "comm", "engine_name",
+           "engine_fallback_reason", "selftest_report"]
 
 
 class NotInitializedError(ValueError):
@@ -42,6 +50,8 @@ class _State:
         self.group = None
         self.comm = None
         self.engine = "torch"
+        self.engine_fallback = None   # why the native engine was abandoned (HVD_ENGINE_FALLBACK=torch)
+        self.selftest = None          # what the init self-test covered
         self.owns_default_group = False
         self.cpu_affinity = None  # CPU set chosen by utils.affinity (None = left alone)
         self.config = EngineConfig()
@@ -57,6 +67,88 @@ def _env_first(*names, default=None):
         if v not in (None, ""):
             return v
     return default
+
+
+def _comm_device(want):
+    return torch.device("cuda", torch.cuda.current_device()) if want == "rccl" else torch.device("cpu")
+
+
+def _start_native(rk, world, want, cfg, tmo):
+    """Bring the in-tree engine up and prove it.  Returns None on success, else the exception -
+    after every rank has learned through the engine's TCP store that SOME rank failed, so that a
+    fallback (or the exit) is the same decision everywhere."""
+    from .comm import CommError, NativeComm
+
+    problem = None
+    comm = None
+    try:
+        comm = NativeComm(rk, world, _S.local_rank,
+                          os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                          int(os.environ.get("MASTER_PORT", "29500")),
+                          tmo, cfg.stall_warning_s,
+                          use_rccl=(want == "rccl"), timeline=cfg.timeline,
+                          allreduce_algo=cfg.allreduce_algo)
+        if cfg.init_selftest:
+            from .selftest import run_init_selftest
+
+            _S.selftest = run_init_selftest(comm, rk, world, _comm_device(want))
+    except CommError as e:
+        problem = e
+    # agreement: a rank whose own test passed must not run ahead of one that is about to leave
+    if comm is not None and world > 1 and getattr(comm, "lib", None) is not None:
+        try:
+            verdicts = comm.all_gather_object("ok" if problem is None else "failed: %s" % problem, world)
+            if problem is None:
+                bad = [(r, v) for r, v in enumerate(verdicts) if v != "ok"]
+                if bad:
+                    problem = CommError("rank %d reported: %s" % bad[0])
+        except CommError as e:  # the control plane itself is gone
+            problem = problem or e
+    if problem is None:
+        _S.comm = comm
+        _S.backend = want
+        return None
+    if comm is not None:
+        try:
+            comm.shutdown()
+        except Exception:  # pragma: no cover - teardown best effort
+            pass
+    return problem
+
+
+def _start_torch(rk, world, want, cfg, tmo_s):
+    if dist.is_initialized():
+        _S.group = dist.group.WORLD
+        _S.owns_default_group = False
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ["RANK"] = str(rk)
+        os.environ["WORLD_SIZE"] = str(world)
+        tmo = datetime.timedelta(seconds=tmo_s)
+        kwargs = {}
+        if want == "rccl":
+            kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
+            # Collectives on a HIGH-priority stream: besides pre-empting compute at
+            # workgroup dispatch, a priority class of its own gives the stream a hardware
+            # queue of its own.  A normal-priority pool stream shared queue 4 with the
+            # compute stream (rocprofv3 trace, profiles/r1_notes.md): the collective's
+            # wait for the weight-gradient stream then sat in front of the compute
+            # stream's packets and stalled it 100-150 us per bucket.
+            if cfg.high_priority_comm and hasattr(dist, "ProcessGroupNCCL"):
+                try:
+                    kwargs["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                except Exception:  # pragma: no cover - older torch
+                    pass
+        dist.init_process_group(backend="nccl" if want == "rccl" else "gloo",
+                                init_method="env://", rank=rk, world_size=world,
+                                timeout=tmo, **kwargs)
+        _S.group = dist.group.WORLD
+        _S.owns_default_group = True
+    _S.backend = want
+    from .comm import TorchComm
+
+    _S.comm = TorchComm(want, _S.group)
 
 
 def init(backend: str | None = None, timeout_s: float | None = None) -> None:
@@ -118,50 +210,25 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
                           "planned statically and launched the moment their last gradient arrives "
                           "(there is no negotiation cycle to pace)" % cfg.cycle_time_ms)
         force = bool(cfg.force_collectives)
+        tmo = timeout_s or cfg.collective_timeout_s
         if (world > 1 or force) and engine == "native":
-            from .comm import NativeComm
+            problem = _start_native(rk, world, want, cfg, tmo)
+            if problem is not None:
+                if cfg.engine_fallback != "torch":
+                    raise problem
+                import sys
 
-            _S.comm = NativeComm(rk, world, _S.local_rank,
-                                 os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                                 int(os.environ.get("MASTER_PORT", "29500")),
-                                 timeout_s or cfg.collective_timeout_s, cfg.stall_warning_s,
-                                 use_rccl=(want == "rccl"), timeline=cfg.timeline,
-                                 allreduce_algo=cfg.allreduce_algo)
-            _S.backend = want
-        elif world > 1 or force:
-            if dist.is_initialized():
-                _S.group = dist.group.WORLD
-                _S.owns_default_group = False
-            else:
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29500")
-                os.environ["RANK"] = str(rk)
-                os.environ["WORLD_SIZE"] = str(world)
-                tmo = datetime.timedelta(seconds=timeout_s or cfg.collective_timeout_s)
-                kwargs = {}
-                if want == "rccl":
-                    kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
-                    # Collectives on a HIGH-priority stream: besides pre-empting compute at
-                    # workgroup dispatch, a priority class of its own gives the stream a hardware
-                    # queue of its own.  A normal-priority pool stream shared queue 4 with the
-                    # compute stream (rocprofv3 trace, profiles/r1_notes.md): the collective's
-                    # wait for the weight-gradient stream then sat in front of the compute
-                    # stream's packets and stalled it 100-150 us per bucket.
-                    if cfg.high_priority_comm and hasattr(dist, "ProcessGroupNCCL"):
-                        try:
-                            kwargs["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-                        except Exception:  # pragma: no cover - older torch
-                            pass
-                dist.init_process_group(backend="nccl" if want == "rccl" else "gloo",
-                                        init_method="env://", rank=rk, world_size=world,
-                                        timeout=tmo, **kwargs)
-                _S.group = dist.group.WORLD
-                _S.owns_default_group = True
-            _S.backend = want
-            from .comm import TorchComm
+                print("[ddl rank %d] native engine abandoned, continuing on torch.distributed (HVD_ENGINE_FALLBACK=torch): %s"
+                      % (rk, problem), file=sys.stderr, flush=True)
+                _S.engine_fallback = str(problem).splitlines()[0][:300]
+                _S.engine = engine = "torch"
+        if (world > 1 or force) and engine == "torch":
+            _start_torch(rk, world, want, cfg, tmo)
+            if cfg.init_selftest:
+                from .selftest import run_init_selftest
 
-            _S.comm = TorchComm(want, _S.group)
-        else:
+                _S.selftest = run_init_selftest(_S.comm, rk, world, _comm_device(want))
+        if _S.comm is None:
             _S.backend = "single"
         _S.initialized = True
 
@@ -247,6 +314,16 @@ def trivial() -> bool:
 
 def engine_name() -> str:
     return _S.engine
+
+
+def engine_fallback_reason():
+    """None, or why HVD_ENGINE_FALLBACK=torch had to replace the native engine in this job."""
+    return _S.engine_fallback
+
+
+def selftest_report():
+    """What the init self-test covered ({"algos", "dtypes", "numel"}); None when it did not run."""
+    return _S.selftest
 
 
 def device() -> torch.device:

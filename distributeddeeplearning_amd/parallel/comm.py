@@ -3,9 +3,9 @@
 Two interchangeable implementations of one small interface (``all_reduce``, ``broadcast``,
 ``all_gather_into``, ``barrier``, object broadcast/gather; every tensor op returns a ``Work``):
 
-* ``TorchComm``  — ``torch.distributed`` process group: RCCL over xGMI on GPUs (backend "nccl"
-  IS RCCL on ROCm), gloo on CPU.  Default.
-* ``NativeComm`` — the in-tree C++ engine (``csrc/engine``; ``HVD_ENGINE=native``): TCP
+* ``TorchComm``  — ``torch.distributed`` process group: gloo on CPU (the default there), RCCL
+  through c10d on GPUs only when ``HVD_ENGINE=torch`` asks for it.
+* ``NativeComm`` — the in-tree C++ engine (``csrc/engine``), the DEFAULT data plane on GPUs: TCP
   rendezvous store instead of MPI/c10d, a background communication thread with a submit queue
   and integer handles, header-checked ring collectives over TCP for host tensors, RCCL called
   directly on a dedicated high-priority HIP stream with event hand-offs for device tensors,
@@ -124,11 +124,42 @@ _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.bfloat16: 3
            torch.uint8: 5, torch.float16: 6}
 _OPS = {"sum": 0, "average": 1, "min": 2, "max": 3}
 _ALGOS = {"rccl": 0, "twoshot": 1, "oneshot": 2}
-# HVD_ALLREDUCE_ALGO=auto: buckets up to this size go through the one-shot kernel (latency-bound:
-# one hop instead of RCCL's ring/tree steps), up to _AUTO_TWOSHOT_MAX through two-shot (all seven
-# xGMI links busy, 2 x S/8 per link), larger ones through RCCL
-ONE_SHOT_MAX_BYTES = 512 * 1024
-_AUTO_TWOSHOT_MAX = 64 * 1024 * 1024
+# HVD_ALLREDUCE_ALGO=auto picks the all-reduce by bucket size from a MEASURED table (written by
+# ``benchmarks/allreduce_bw.py --algo all --table <path>`` on the node the job runs on; path in
+# HVD_ALLREDUCE_TABLE, default profiles/allreduce_table_n<world>.json).  There are no built-in
+# thresholds: without the table ``auto`` refuses to start and says how to produce it.
+
+
+def default_table_path(world):
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    return os.environ.get("HVD_ALLREDUCE_TABLE") or os.path.join(root, "profiles", "allreduce_table_n%d.json" % world)
+
+
+def load_algo_table(world, path=None):
+    """[(max_bytes, algo), ...] ascending, the last entry open-ended; raises CommError when the table
+    is missing, was measured for another world size, or names an unknown algorithm."""
+    import json
+
+    path = path or default_table_path(world)
+    if not os.path.isfile(path):
+        raise CommError(
+            "HVD_ALLREDUCE_ALGO=auto needs the measured table %s (not found).  Produce it on this node with\n"
+            "  python -m torch.distributed.run --nproc-per-node %d benchmarks/allreduce_bw.py --algo all --table %s\n"
+            "or choose HVD_ALLREDUCE_ALGO=rccl|twoshot|oneshot explicitly." % (path, world, path))
+    with open(path) as fh:
+        doc = json.load(fh)
+    if int(doc.get("world", -1)) != int(world):
+        raise CommError("all-reduce table %s was measured with %s ranks, this job has %d" % (path, doc.get("world"), world))
+    rows = []
+    for ent in doc.get("thresholds", []):
+        algo, mx = ent.get("algo"), ent.get("max_bytes")
+        if algo not in _ALGOS:
+            raise CommError("all-reduce table %s names unknown algorithm %r" % (path, algo))
+        rows.append((float("inf") if mx is None else int(mx), algo))
+    rows.sort(key=lambda r: r[0])
+    if not rows or rows[-1][0] != float("inf"):
+        raise CommError("all-reduce table %s has no open-ended last entry" % path)
+    return rows
 
 
 class _HostWork(Work):
@@ -276,6 +307,8 @@ class NativeComm:
         self.rccl = False
         self.has_rccl_comm = False
         self.algo = "rccl"
+        self.force_algo = None     # "rccl" | "twoshot" | "oneshot": overrides the policy (benchmarks, self-test)
+        self.algo_table = None     # HVD_ALLREDUCE_ALGO=auto: [(max_bytes, algo)] from the measured table
         self._regions = []
         # broadcast_object blobs are authenticated with a per-job secret when the launcher
         # provides one (DDL_JOB_TOKEN): nothing unauthenticated is ever unpickled
@@ -297,17 +330,25 @@ class NativeComm:
 
     def _init_algo(self, algo):
         algo = (algo or "rccl").lower()
-        if algo not in ("rccl", "twoshot", "oneshot", "auto"):
-            raise CommError("unknown HVD_ALLREDUCE_ALGO %r (expected rccl|twoshot|oneshot|auto)" % algo)
+        if algo not in ("rccl", "twoshot", "oneshot", "auto", "manual"):
+            raise CommError("unknown HVD_ALLREDUCE_ALGO %r (expected rccl|twoshot|oneshot|auto|manual)" % algo)
         if algo == "rccl" or self.size == 1:
             return
+        if algo == "auto":
+            self.algo_table = load_algo_table(self.size)   # refuses (CommError) until measured
         if self.size > 8:
             raise CommError("HVD_ALLREDUCE_ALGO=%s spans one node of at most 8 GPUs" % algo)
         from ..ops import kernels as _k
 
         fn = ctypes.cast(_k.lib().ddl_xgmi_allreduce, ctypes.c_void_p)
         blocks = int(os.environ.get("HVD_XGMI_BLOCKS", "16"))
-        spins = int(os.environ.get("HVD_XGMI_SPIN_LIMIT", "20000000"))
+        # Spin budget of the kernel's flag waits.  One poll (sc0 sc1 load + s_sleep 8 + loop) takes
+        # ~0.5-1 us, so the 20 M-poll default gave up after a few tens of seconds - far below the
+        # collective timeout every other path honours (a rank that checkpoints, validates or stalls in
+        # its loader is legitimately late).  The budget now follows HVD_COLLECTIVE_TIMEOUT_S at a
+        # conservative 0.4 us per poll (the kernel can only be MORE patient than the watchdog, which
+        # then is the one that declares the collective dead); HVD_XGMI_SPIN_LIMIT overrides.
+        spins = int(os.environ.get("HVD_XGMI_SPIN_LIMIT", "0")) or max(int(self.timeout_s * 2.5e6), 20000000)
         if self.lib.ddl_xgmi_init(fn, blocks, ctypes.c_longlong(spins)) != 0:
             raise CommError("xGMI plane init failed: %s" % self.lib.ddl_rccl_last_error().decode())
         self.algo = algo
@@ -328,12 +369,25 @@ class NativeComm:
         if self.algo == "rccl" or op not in ("sum", "average") or \
                 tensor.dtype not in (torch.float32, torch.bfloat16):
             return 0
+        if self.force_algo is not None:
+            return _ALGOS[self.force_algo]
+        if self.algo == "manual":
+            return 0
         if self.algo != "auto":
             return _ALGOS[self.algo]
         nbytes = tensor.numel() * tensor.element_size()
-        if nbytes <= ONE_SHOT_MAX_BYTES:
-            return 2
-        return 1 if nbytes <= _AUTO_TWOSHOT_MAX else 0
+        for max_bytes, algo in self.algo_table:
+            if nbytes <= max_bytes:
+                return _ALGOS[algo]
+        return 0
+
+    def enabled_algos(self):
+        """Algorithms a gradient bucket can take in this job (the init self-test covers each)."""
+        if self.algo == "rccl" or self.size == 1:
+            return ["rccl"]
+        if self.algo in ("auto", "manual"):
+            return ["rccl", "twoshot", "oneshot"] if self.has_rccl_comm else ["twoshot", "oneshot"]
+        return [self.algo]
 
     @property
     def supports_avg(self):
@@ -430,8 +484,13 @@ class NativeComm:
     def stats(self):
         """{collective name: {"count", "last_ms", "mean_ms", "algo", "bytes"}}: DEVICE time of every
         named device collective, measured by the engine from HIP events."""
-        buf = ctypes.create_string_buffer(1 << 16)
-        n = self.lib.ddl_eng_stats(buf, ctypes.c_longlong(len(buf)))
+        cap = 1 << 16
+        buf = ctypes.create_string_buffer(cap)
+        n = self.lib.ddl_eng_stats(buf, ctypes.c_longlong(cap))
+        if n >= cap:   # the engine reports the required length: grow once and ask again
+            cap = int(n) + 4096
+            buf = ctypes.create_string_buffer(cap)
+            n = self.lib.ddl_eng_stats(buf, ctypes.c_longlong(cap))
         out = {}
         if n <= 0:
             return out

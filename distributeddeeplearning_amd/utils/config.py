@@ -193,6 +193,17 @@ class EngineConfig:
     high_priority_comm: bool = True   # RCCL collectives on a high-priority HIP stream (own hardware queue)
     comm_metrics: bool = True         # per-step exposed-communication time from HIP events (never synchronises)
     per_bucket_update: bool = True    # FusedSGD: update bucket k as soon as the stream has waited for bucket k
+    # one checked all-reduce per enabled algorithm / wire dtype + broadcast + all-gather at init()
+    # (parallel/selftest.py); a wrong word or a timeout ends the job with the engine's diagnosis
+    init_selftest: bool = True
+    # "" = a native engine that fails to start or fails its self-test ends the job (default);
+    # "torch" = every rank then agrees (through the TCP store) to continue on torch.distributed's
+    # RCCL process group and says so on stderr and in hvd.engine_name()
+    engine_fallback: str = ""
+    # after each of the first N optimizer steps (every step with HVD_DEBUG=1) the ranks all-gather a
+    # checksum of their reduced gradients and updated parameters and raise if replicas differ
+    replica_check_steps: int = 2
+    fault_corrupt: Optional[str] = None  # "rank:step": flip one reduced-gradient word there (tests the check)
 
     @classmethod
     def from_env(cls) -> "EngineConfig":
@@ -217,4 +228,8 @@ class EngineConfig:
             high_priority_comm=env_bool("HVD_HIGH_PRIORITY_COMM", True),
             comm_metrics=env_bool("HVD_COMM_METRICS", True),
             per_bucket_update=env_bool("HVD_PER_BUCKET_UPDATE", True),
+            init_selftest=env_bool("HVD_INIT_SELFTEST", True),
+            engine_fallback=(env_str("HVD_ENGINE_FALLBACK", "") or "").lower(),
+            replica_check_steps=env_int("HVD_REPLICA_CHECK_STEPS", 2),
+            fault_corrupt=env_str("HVD_FAULT_CORRUPT", None),
         )
