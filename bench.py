@@ -22,6 +22,11 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The benchmark must yield a number on the first multi-GPU node it ever sees: if the native engine
+# fails to start or fails its checked self-test there, every rank agrees to continue on
+# torch.distributed's RCCL process group - reported on stderr and in the JSON line ("engine",
+# "engine_fallback").  Training scripts keep the strict default (exit non-zero).
+os.environ.setdefault("HVD_ENGINE_FALLBACK", "torch")
 
 import torch
 
@@ -201,6 +206,8 @@ def main(argv=None):
             # gradient exchange: which engine carried it, how long the compute stream sat waiting for
             # it per step (HIP events) and the device time of each bucket's collective
             "engine": hvd.engine_name() if hvd.comm() is not None else "none",
+            "engine_fallback": hvd.engine_fallback_reason(),
+            "selftest": hvd.selftest_report(),
             "allreduce_algo": getattr(hvd.comm(), "algo", "rccl") if hvd.comm() is not None else "none",
             "comm": opt.comm_metrics() if hasattr(opt, "comm_metrics") else None,
             "config": {"model": args.model, "global_batch": global_batch,

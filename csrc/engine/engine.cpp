@@ -189,6 +189,12 @@ void set_device_plane(const DevicePlane* plane) { g_plane = plane; }
 
 struct Header { uint32_t magic; int32_t kind, dtype; int64_t count; uint64_t name_hash; };
 
+// A store server started BEFORE Engine::init by ddl_eng_listen(): rank 0 lets the kernel pick the
+// port (bind to 0), learns the port that was actually bound and publishes it out of band (the
+// torchrun agent's store) - no window in which another process can take a probed-and-closed port.
+static StoreServer* g_prestarted = nullptr;
+static int g_prestarted_port = 0;
+
 class Engine {
 public:
     int rank = 0, size = 1;
@@ -201,7 +207,11 @@ public:
               std::string* err) {
         rank = rank_; size = size_; timeout_s = timeout_s_; stall_warning_s = stall_s;
         const int tmo = (int)(timeout_s * 1000);
-        if (rank == 0) {
+        if (rank == 0 && g_prestarted && (port == g_prestarted_port || port == 0)) {
+            server_ = g_prestarted;         // already listening (ddl_eng_listen)
+            port = g_prestarted_port;
+            g_prestarted = nullptr;
+        } else if (rank == 0) {
             int bound = 0;
             // a single-node job (the rendezvous address is the loopback interface) keeps its control
             // plane off the network; multi-node jobs listen on every interface
@@ -708,6 +718,18 @@ int ddl_eng_init(int rank, int size, const char* addr, int port, double timeout_
     }
     g_engine = e;
     return 0;
+}
+
+// Rank 0 only, before ddl_eng_init: start the control-plane store on `port` (0 = any free port)
+// and return the port actually bound (-1 on failure).  ddl_eng_init(…, that port, …) adopts it.
+int ddl_eng_listen(int port, int loopback_only) {
+    if (ddl::g_prestarted) return ddl::g_prestarted_port;
+    int bound = 0;
+    ddl::StoreServer* s = ddl::store_server_start(port, &bound, loopback_only != 0);
+    if (!s) { g_err = "cannot listen on control port " + std::to_string(port); return -1; }
+    ddl::g_prestarted = s;
+    ddl::g_prestarted_port = bound;
+    return bound;
 }
 
 void ddl_eng_shutdown() {

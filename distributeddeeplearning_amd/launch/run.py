@@ -114,6 +114,13 @@ def build_env(base_env, rank, local_rank, world, local_size, master_addr, master
     return env
 
 
+def remote_command(cwd, assignments, command):
+    """Shell line run by ssh on a remote host: the first line of stdin is the job token."""
+    assigns = " ".join("%s=%s" % (k, shlex.quote(v)) for k, v in assignments.items())
+    return "IFS= read -r DDL_JOB_TOKEN; export DDL_JOB_TOKEN; cd %s && env %s %s" % (
+        shlex.quote(cwd), assigns, " ".join(shlex.quote(c) for c in command))
+
+
 def _pump(stream, tag, sink, lock):
     for raw in iter(stream.readline, b""):
         with lock:
@@ -128,10 +135,15 @@ def launch(command, np_total, hosts=None, exports=None, tag_output=True, timeout
     hosts = hosts or [("localhost", np_total)]
     exports = dict(exports or {})
     # per-job secret: the engine's control plane only unpickles objects signed with it
-    if "DDL_JOB_TOKEN" not in exports and "DDL_JOB_TOKEN" not in os.environ:
-        import secrets
+    # (a token already present in the launcher's environment is the job's token: ssh-started
+    # ranks do not inherit the environment, so it has to travel with the exports all the same)
+    if "DDL_JOB_TOKEN" not in exports:
+        if os.environ.get("DDL_JOB_TOKEN"):
+            exports["DDL_JOB_TOKEN"] = os.environ["DDL_JOB_TOKEN"]
+        else:
+            import secrets
 
-        exports["DDL_JOB_TOKEN"] = secrets.token_hex(16)
+            exports["DDL_JOB_TOKEN"] = secrets.token_hex(16)
     sink = sink or sys.stdout
     placement = assign_slots(hosts, np_total)
     first_host = placement[0][1]
@@ -141,19 +153,28 @@ def launch(command, np_total, hosts=None, exports=None, tag_output=True, timeout
     procs, threads, lock = [], [], threading.Lock()
     for rank, host, lrank, lsize in placement:
         env = build_env(os.environ, rank, lrank, np_total, lsize, master_addr, master_port, exports)
+        secret = None
         if host in _LOCAL_NAMES or host == socket.gethostname():
             argv = list(command)
             penv = env
         else:
+            # the job token never appears on a command line (`ps` shows those): the remote shell
+            # reads it from ssh's stdin, everything else travels as env assignments
             keys = ["RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR",
-                    "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"] + list(exports)
-            assigns = " ".join("%s=%s" % (k, shlex.quote(env[k])) for k in keys)
-            remote = "cd %s && env %s %s" % (shlex.quote(os.getcwd()), assigns,
-                                             " ".join(shlex.quote(c) for c in command))
-            argv = ["ssh", "-o", "StrictHostKeyChecking=no", host, remote]
+                    "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"] + [k for k in exports if k != "DDL_JOB_TOKEN"]
+            argv = ["ssh", "-o", "StrictHostKeyChecking=no", host,
+                    remote_command(os.getcwd(), {k: env[k] for k in keys}, command)]
             penv = dict(os.environ)
+            secret = (env.get("DDL_JOB_TOKEN", "") + "\n").encode()
         p = subprocess.Popen(argv, env=penv, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                             stdin=subprocess.PIPE if secret is not None else None,
                              start_new_session=True)
+        if secret is not None:
+            try:
+                p.stdin.write(secret)
+                p.stdin.close()
+            except OSError:  # ssh died at once: the exit-code watch below reports it
+                pass
         procs.append(p)
         tag = "[%d]<%s>: " % (rank, host) if tag_output else ""
         t = threading.Thread(target=_pump, args=(p.stdout, tag, sink, lock), daemon=True)

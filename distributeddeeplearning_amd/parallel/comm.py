@@ -245,13 +245,15 @@ class _DeviceWork(Work):
         return self.done or self.comm.lib.ddl_eng_poll(ctypes.c_longlong(self.handle)) >= 2
 
 
-def engine_port(rank, master_addr, master_port, timeout_s=300.0):
+def engine_port(rank, master_addr, master_port, timeout_s=300.0, lib=None):
     """Control port of the native engine's TCP store.
 
     ``DDL_ENGINE_PORT`` wins.  Under ``torch.distributed.run`` the agent already hosts a store on
-    MASTER_PORT: rank 0 then takes any free port and publishes it there (a port "next to"
-    MASTER_PORT may be taken on a busy host).  Otherwise - our own launcher, ``mpirun`` - the
-    engine listens on MASTER_PORT + 1."""
+    MASTER_PORT: rank 0 lets the ENGINE bind any free port (``ddl_eng_listen(0)``: the socket that
+    is probed is the socket that serves, nobody can take the port in between) and publishes the
+    port it got there, under a key that carries the run id AND the restart count - after an
+    elastic worker restart the other ranks must not read the previous attempt's (dead) port.
+    Otherwise - our own launcher, ``mpirun`` - the engine listens on MASTER_PORT + 1."""
     explicit = os.environ.get("DDL_ENGINE_PORT")
     if explicit:
         return int(explicit)
@@ -259,13 +261,19 @@ def engine_port(rank, master_addr, master_port, timeout_s=300.0):
         try:
             store = dist.TCPStore(master_addr, int(master_port), is_master=False,
                                   timeout=datetime.timedelta(seconds=timeout_s))
-            key = "ddl/engine_port/%s" % os.environ.get("TORCHELASTIC_RUN_ID", "0")
+            key = "ddl/engine_port/%s/%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "0"),
+                                             os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
             if rank == 0:
-                import socket
+                loopback = master_addr in ("127.0.0.1", "localhost")
+                port = -1
+                if lib is not None and hasattr(lib, "ddl_eng_listen"):
+                    port = int(lib.ddl_eng_listen(0, 1 if loopback else 0))
+                if port <= 0:   # older engine library: probe (racy, kept as a last resort)
+                    import socket
 
-                with socket.socket() as sk:
-                    sk.bind(("127.0.0.1" if master_addr in ("127.0.0.1", "localhost") else "", 0))
-                    port = sk.getsockname()[1]
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1" if loopback else "", 0))
+                        port = sk.getsockname()[1]
                 store.set(key, str(port))
                 return port
             return int(store.get(key).decode())
@@ -299,7 +307,7 @@ class NativeComm:
         lib.ddl_eng_device_wait.argtypes = [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_double]
         lib.ddl_eng_device_wait_host.argtypes = [ctypes.c_longlong, ctypes.c_double]
         self.rank, self.size, self.timeout_s = rank, size, float(timeout_s)
-        port = engine_port(rank, master_addr, master_port, timeout_s)
+        port = engine_port(rank, master_addr, master_port, timeout_s, lib)
         rc = lib.ddl_eng_init(rank, size, master_addr.encode(), port, ctypes.c_double(timeout_s),
                               ctypes.c_double(stall_warning_s))
         if rc != 0:

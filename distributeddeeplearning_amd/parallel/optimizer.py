@@ -165,6 +165,10 @@ class _DistributedMixin:
         self._ddl_order_checked = False
         self._ddl_direct_seen = set()
         self._ddl_fault = _parse_fault(cfg.fault_inject)
+        self._ddl_corrupt = _parse_fault(cfg.fault_corrupt)
+        # replica check: after each of the first N steps (every step in debug mode) all ranks compare
+        # checksums of the reduced gradients and of the updated parameters
+        self._ddl_check_steps = (1 << 62) if cfg.debug else max(int(cfg.replica_check_steps), 0)
         if arena is None:
             arena = getattr(self, "arena", None)  # fused optimizers bring their own arena
         if arena is None:
@@ -331,6 +335,76 @@ class _DistributedMixin:
                           "%d places; overlap will be reduced" % (inversions, len(seen)))
         self._ddl_order_seen = []
 
+    # -- replica check ----------------------------------------------------------------------
+    @staticmethod
+    def _ddl_checksum(t):
+        """[sum of words, position-weighted sum of words] of a tensor's bit pattern, wrapping int64:
+        equal tensors give equal pairs, a flipped, missing or moved word changes them."""
+        flat = t.detach().reshape(-1)
+        words = flat.view(torch.int16 if flat.element_size() == 2 else torch.int32).to(torch.int64)
+        idx = torch.arange(words.numel(), device=words.device, dtype=torch.int64) % 65521 + 1
+        return torch.stack([words.sum(), (words * idx).sum()])
+
+    def _ddl_replica_check(self, stage):
+        """Collective.  ``stage`` = "gradients" (after the exchange, before the update) or
+        "parameters" (after the update).  An xGMI coherence bug, a collective that skipped a
+        shard or a rank that missed a broadcast shows up HERE, on step 1, as an exception naming the
+        arena and the ranks - not hours later as a diverging loss."""
+        if _b.trivial() or _b.size() == 1:
+            return
+        arena = self._ddl_arena
+        names, sums = [], []
+        for dt in sorted(arena.plans, key=str):
+            key = str(dt).replace("torch.", "")
+            if stage == "gradients":
+                names.append("grad." + key)
+                sums.append(self._ddl_checksum(arena.grads[dt]))
+            else:
+                src = None
+                masters = getattr(self, "master", None)
+                if isinstance(masters, dict) and dt in masters:
+                    src = masters[dt]
+                elif getattr(arena, "params", None) and dt in arena.params:
+                    src = arena.params[dt]
+                if src is None:   # parameters are not flattened: checksum them one by one
+                    parts = [self._ddl_checksum(arena.named[seg.index][1]) for seg in arena.plans[dt].segments]
+                    names.append("param." + key)
+                    sums.append(torch.stack(parts).sum(0))
+                else:
+                    names.append("param." + key)
+                    sums.append(self._ddl_checksum(src))
+        mine = torch.stack(sums).reshape(-1).contiguous()
+        if _b.backend_name() == "gloo" and mine.is_cuda:
+            mine = mine.cpu()
+        world = _b.size()
+        out = torch.zeros((world, mine.numel()), dtype=torch.int64, device=mine.device)
+        w = _b.comm().all_gather_into(out, mine, "replica_check.%s" % stage)
+        if not w.wait(_b.engine_config().collective_timeout_s):
+            raise RuntimeError("replica check timed out")
+        rows = out.cpu().view(world, len(names), 2)
+        for k, name in enumerate(names):
+            ref = rows[0, k]
+            differing = [r for r in range(world) if not torch.equal(rows[r, k], ref)]
+            if differing:
+                raise RuntimeError(
+                    "replicas differ after step %d: %s of %s on rank(s) %s do not match rank 0 "
+                    "(engine %s, all-reduce %s) - the gradient exchange delivered different data to "
+                    "different ranks" % (self._ddl_step_count + (0 if stage == "gradients" else 0), stage, name,
+                                         differing, _b.engine_name(),
+                                         getattr(_b.comm(), "algo", "?")))
+
+    def _ddl_checking(self):
+        return self._ddl_step_count < self._ddl_check_steps and not _b.trivial() and _b.size() > 1
+
+    def _ddl_maybe_corrupt(self):
+        if self._ddl_corrupt is not None:
+            crank, cstep = self._ddl_corrupt
+            if _b.rank() == crank and self._ddl_step_count == cstep:
+                for dt in sorted(self._ddl_arena.grads, key=str):
+                    g = self._ddl_arena.grads[dt].view(-1)
+                    g[g.numel() // 2] += 1.0   # HVD_FAULT_CORRUPT: one wrong word on one rank
+                    break
+
     def _ddl_reset_buckets(self):
         self._ddl_direct_seen.clear()
         for st in self._ddl_buckets:
@@ -341,11 +415,18 @@ class _DistributedMixin:
     def step(self, closure=None):
         base = super(self.__class__, self)
         per_bucket = getattr(base, "step_bucket", None)
-        if per_bucket is None or closure is not None or not _b.engine_config().per_bucket_update:
+        checking = self._ddl_checking()
+        if per_bucket is None or closure is not None or not _b.engine_config().per_bucket_update or checking:
             self.synchronize()
             self._ddl_reset_buckets()
+            self._ddl_maybe_corrupt()
+            if checking:
+                self._ddl_replica_check("gradients")
+            out = base.step(closure)
+            if checking:
+                self._ddl_replica_check("parameters")
             self._ddl_step_count += 1
-            return base.step(closure)
+            return out
         # fused optimizer: wait for bucket k, update bucket k, wait for bucket k+1 ... - the
         # update of the early buckets runs while the tail of the exchange is still in flight
         self._ddl_prepare_sync()

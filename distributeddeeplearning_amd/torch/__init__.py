@@ -8,6 +8,7 @@ surface named there (``shutdown``, ``local_size``, in-place/async variants, ``al
 """
 from ..parallel.backend import (init, shutdown, is_initialized, rank, size, local_rank,
                                 local_size, cross_rank, cross_size, barrier, comm, engine_name,
+                                engine_fallback_reason, selftest_report,
                                 backend_name, NotInitializedError)
 from ..parallel.collectives import (allreduce, allreduce_, allreduce_async, allreduce_async_,
                                     allgather, allgather_async, broadcast, broadcast_,
@@ -48,4 +49,5 @@ __all__ = [
     "DistributedOptimizer", "Compression", "callbacks", "BroadcastGlobalVariablesHook",
     "Sum", "Average", "Min", "Max", "mpi_threads_supported", "nccl_built", "gloo_built",
     "NotInitializedError", "comm", "engine_name", "backend_name",
+    "engine_fallback_reason", "selftest_report",
 ]

@@ -103,6 +103,37 @@ def scenario_optimizer_equivalence():
     hvd.shutdown()
 
 
+def scenario_replica_check():
+    """HVD_FAULT_CORRUPT=rank:step flips one word of one rank's REDUCED gradients; the replica
+    check of DistributedOptimizer must raise on every rank at that step."""
+    hvd.init()
+    r = hvd.rank()
+    model = _tiny_model()
+    hvd.broadcast_parameters(model.state_dict(), root_rank=0)
+    fused = os.environ.get("TEST_FUSED", "0") == "1"
+    if fused:
+        from distributeddeeplearning_amd.optim import FusedSGD
+
+        opt = FusedSGD(model.named_parameters(), lr=0.05, momentum=0.9)
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    opt = hvd.DistributedOptimizer(opt, named_parameters=model.named_parameters())
+    g = torch.Generator().manual_seed(5 + r)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    y = torch.randint(0, 5, (4,), generator=g)
+    raised_at, msg = None, ""
+    for step in range(4):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        try:
+            opt.step()
+        except RuntimeError as e:
+            raised_at, msg = step, str(e)
+            break
+    emit(rank=r, raised_at=raised_at, msg=msg, report=hvd.selftest_report())
+    hvd.shutdown()
+
+
 def scenario_checkpoint_resume():
     from distributeddeeplearning_amd.optim import FusedSGD
     from distributeddeeplearning_amd.utils import checkpoint
