@@ -24,7 +24,7 @@ from ..parallel import backend as _b
 from ..parallel import collectives as _c
 from ..parallel import functions as _f
 
-__all__ = ["save", "load", "latest_epoch", "resume", "checkpoint_path", "model_dir"]
+__all__ = ["save", "load", "latest_epoch", "resume", "checkpoint_path", "model_dir", "restore_rng"]
 
 _PATTERN = re.compile(r"^checkpoint-(\d+)\.pt$")
 
@@ -60,7 +60,7 @@ def save(directory, epoch, model, optimizer=None, scheduler=None, extra=None, ke
     payload = {
         "epoch": int(epoch),
         "model": _export_model_state(model, optimizer),
-        "rng": {"torch": torch.get_rng_state()},
+        "rng": _rng_state(),
         "extra": extra or {},
     }
     if optimizer is not None:
@@ -81,6 +81,24 @@ def save(directory, epoch, model, optimizer=None, scheduler=None, extra=None, ke
     return path
 
 
+def _rng_state():
+    """Generator states a resumed run needs to continue the SAME random sequence (data order of
+    the synthetic loader, dropout-free model: the loaders draw from torch's generators)."""
+    state = {"torch": torch.get_rng_state()}
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        state["cuda"] = torch.cuda.get_rng_state()
+    return state
+
+
+def restore_rng(state):
+    if not state:
+        return
+    if "torch" in state:
+        torch.set_rng_state(state["torch"].to(torch.uint8).cpu())
+    if "cuda" in state and torch.cuda.is_available():
+        torch.cuda.set_rng_state(state["cuda"].to(torch.uint8).cpu())
+
+
 def _list_epochs(directory):
     if not directory or not os.path.isdir(directory):
         return []
@@ -98,7 +116,9 @@ def latest_epoch(directory) -> int:
     return max(epochs) if epochs else 0
 
 
-def load(path, model=None, optimizer=None, scheduler=None, map_location="cpu"):
+def load(path, model=None, optimizer=None, scheduler=None, map_location="cpu", rng=True):
+    """Restore ``model`` / ``optimizer`` / ``scheduler`` (each optional) from ``path`` and, with
+    ``rng=True``, the random generators the checkpoint recorded.  Safe loader only."""
     payload = torch.load(path, map_location=map_location, weights_only=True)
     if model is not None:
         own = model.state_dict()
@@ -112,11 +132,24 @@ def load(path, model=None, optimizer=None, scheduler=None, map_location="cpu"):
             raise KeyError("model entries missing from checkpoint: %s" % sorted(missing)[:5])
     if optimizer is not None and "optimizer" in payload:
         optimizer.load_state_dict(payload["optimizer"])
-        refresh = getattr(optimizer, "refresh_master_from_params", None)
-        if callable(refresh) and model is not None:
-            optimizer.load_master_from_state(payload["model"], model)
+    if optimizer is not None and model is not None:
+        # an optimizer with fp32 master weights (bf16 compute) takes them from the checkpoint's fp32
+        # model entries: also when the file carries no optimizer state (fine-tuning from weights
+        # only), and bit-exactly when it does (the entries ARE the saved masters)
+        masters = getattr(optimizer, "load_master_from_state", None)
+        if callable(masters):
+            masters(payload["model"], model)
     if scheduler is not None and "scheduler" in payload:
         scheduler.load_state_dict(payload["scheduler"])
+    if model is not None:
+        try:  # parameters were rewritten: derived copies (transposed filters of the HIP path) are stale
+            from ..ops import hip_ops
+
+            hip_ops.weights_changed()
+        except Exception:  # pragma: no cover - ops layer unavailable
+            pass
+    if rng:
+        restore_rng(payload.get("rng"))
     return payload
 
 
