@@ -282,3 +282,46 @@ def test_comm_dtype_fp32_keeps_gradient_arenas_in_fp32(monkeypatch):
     seg = opt.arena.plans[torch.bfloat16].segments[0]
     master = opt.master[torch.bfloat16][seg.offset: seg.offset + seg.numel].view(8, 16)
     assert torch.allclose(master, w0 - 0.1 * g, atol=1e-7)
+
+
+def test_bucket_plan_resnet152_tensors_reverse_order_caps_and_tail():
+    """BASELINE config 5's model: 467 gradient tensors (155 conv + 310 BN + 2 fc),
+    planned in reverse registration order, every bucket within the byte caps, the tail bucket (the
+    stem, ready only when backward ends) at most 256 KiB."""
+    from distributeddeeplearning_amd.models import resnet152
+    from distributeddeeplearning_amd.parallel.bucket import GradArena, arena_options
+    from distributeddeeplearning_amd.utils.config import EngineConfig
+
+    model = resnet152(num_classes=1000)
+    for m in model.modules():   # the compute layout: bf16 conv / fc weights, fp32 BatchNorm and bias
+        w = getattr(m, "weight", None)
+        if w is not None and w.dim() > 1:
+            w.data = w.data.to(torch.bfloat16)
+    named = list(model.named_parameters())
+    assert len(named) == 467 and sum(p.numel() for _, p in named) == 60192808
+    cfg = EngineConfig()
+    arena = GradArena(named, **arena_options(cfg))
+    order = {n: i for i, (n, _) in enumerate(named)}
+    for dt, plan in arena.plans.items():
+        es = torch.empty((), dtype=dt).element_size()
+        idx = [order[s.name] for s in plan.segments]
+        assert idx == sorted(idx, reverse=True)                 # reverse registration = backward order
+        assert [s.name for b in plan.buckets for s in b.segments] == [s.name for s in plan.segments]
+        biggest_tensor = max(s.numel for s in plan.segments) * es
+        for k, b in enumerate(plan.buckets):
+            nbytes = (b.end - b.start) * es
+            cap = cfg.first_bucket_bytes if k == 0 else cfg.fusion_threshold
+            assert nbytes <= max(cap, biggest_tensor), (dt, k, nbytes)
+            assert b.start % 8 == 0                             # 16-byte aligned for either dtype
+        tail = plan.buckets[-1]
+        if plan.numel * es > 4 * cfg.tail_bucket_bytes:
+            # the stem's gradients (ready only when backward ends) travel in a bucket of their own
+            assert (tail.end - tail.start) * es <= cfg.tail_bucket_bytes, (dt, (tail.end - tail.start) * es)
+            assert tail.segments[-1].name == "conv1.weight"
+        else:
+            # an arena below 1 MiB (the fp32 BatchNorm / bias arena: 610 KB here) is ONE latency-bound
+            # bucket: splitting it would add a collective launch (~65 us, profiles/r1_notes.md) to hide ~2 us
+            assert len(plan.buckets) == 1
+        assert plan.buckets[0].segments[0].name.startswith("fc.")
+    nb = {str(dt): len(plan.buckets) for dt, plan in arena.plans.items()}
+    assert nb["torch.bfloat16"] >= 5 and nb["torch.float32"] == 1, nb

@@ -97,6 +97,59 @@ hvd.shutdown()
     assert "g" in rec["stats"] and rec["g_ms"] >= 0 and rec["stream"]
 
 
+def test_resnet152_three_steps_with_forced_collectives():
+    """BASELINE config 5's model through the whole exchange path on the one GPU:
+    467 gradient tensors in >= 6 buckets, every bucket's all-reduce launched by the engine's comm
+    thread each step, the exposed-communication and per-bucket device times reported, the loss of a
+    fixed batch falling."""
+    code = r'''
+import os, json, torch
+os.environ["HVD_FORCE_COLLECTIVES"] = "1"
+os.environ["MASTER_PORT"] = str(33500 + os.getpid() % 2000)
+import distributeddeeplearning_amd.torch as hvd
+from distributeddeeplearning_amd.models import resnet152
+from distributeddeeplearning_amd.ops import functional as ops
+from distributeddeeplearning_amd.optim import FusedSGD
+hvd.init()
+c = hvd.comm()
+dev = torch.device("cuda", 0)
+torch.manual_seed(3)
+m = resnet152(num_classes=100, zero_init_residual=True).to_compute(dev, torch.bfloat16).train()
+opt = hvd.DistributedOptimizer(FusedSGD(m.named_parameters(), lr=0.02, momentum=0.9),
+                               named_parameters=m.named_parameters())
+x = torch.rand(8, 3, 224, 224, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+y = torch.randint(0, 100, (8,), device=dev)
+before = c.launch_counts()["rccl"]
+losses = []
+for it in range(4):
+    opt.zero_grad()
+    loss = ops.softmax_cross_entropy(m(x), y)
+    loss.backward()
+    opt.step()
+    losses.append(float(loss))
+torch.cuda.synchronize()
+import time; time.sleep(0.3)
+opt.zero_grad(); ops.softmax_cross_entropy(m(x), y).backward(); opt.step(); torch.cuda.synchronize()
+nb = sum(len(p.buckets) for p in opt.arena.plans.values())
+print("RESULT " + json.dumps({"losses": losses, "buckets": nb, "launched": c.launch_counts()["rccl"] - before,
+      "metrics": opt.comm_metrics(), "tensors": len(list(m.parameters())), "engine": hvd.engine_name(),
+      "selftest": hvd.selftest_report(), "inversions": getattr(opt, "_ddl_order_inversions", None)}))
+hvd.shutdown()
+'''
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads(out.stdout.split("RESULT ", 1)[1].splitlines()[0])
+    print(rec)
+    assert rec["engine"] == "native" and rec["tensors"] == 467 and rec["buckets"] >= 6
+    assert rec["launched"] == rec["buckets"] * 5
+    assert all(l == l for l in rec["losses"]) and rec["losses"][-1] < rec["losses"][0]
+    met = rec["metrics"]
+    assert met["comm_exposed_ms"] is not None and 0 <= met["comm_exposed_ms"] < 5.0, met
+    assert len(met["bucket_ms"]) == rec["buckets"] and all(v >= 0 for v in met["bucket_ms"].values()), met
+    assert rec["selftest"] and "rccl" in rec["selftest"]["algos"]
+    assert rec["inversions"] is not None and rec["inversions"] <= 467 // 4    # arrival order ~ the static plan
+
+
 def test_bucket_is_complete_when_its_collective_runs():
     """Gating of the gradient exchange: right before every bucket's all-reduce the same gate (event
     on the producer stream -> engine stream) feeds an all-gather of the bucket into a snapshot.

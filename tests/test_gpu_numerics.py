@@ -179,6 +179,93 @@ def test_loss_trajectory_resnet50_20_steps_hip_bf16_vs_aten_fp32():
     _compare_trajectories(hip, ref, band=0.20, final_tol=0.05)
 
 
+# ---- the large-batch recipe end to end: LARS + gradual warm-up + momentum correction -----------------
+class _RefLARS(torch.optim.Optimizer):
+    """Independent fp32 implementation of the rule in optim/fused.py's docstring (You et al. 2017):
+    tensors with ndim > 1 are layer-wise adaptive with weight decay, 1-D tensors take plain momentum SGD."""
+
+    def __init__(self, params, lr, momentum, weight_decay, eta, eps=1e-8):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, eta=eta, eps=eps))
+
+    @torch.no_grad()
+    def step(self):
+        for g in self.param_groups:
+            lr, mu, wd, eta, eps = g["lr"], g["momentum"], g["weight_decay"], g["eta"], g["eps"]
+            for p in g["params"]:
+                v = self.state[p].setdefault("v", torch.zeros_like(p))
+                if p.dim() > 1:
+                    wn, gn = p.norm(), p.grad.norm()
+                    lam = eta * wn / (gn + wd * wn + eps) if (wn > 0 and gn > 0) else 1.0
+                    v.mul_(mu).add_((p.grad + wd * p) * (lr * lam))
+                    p.sub_(v)
+                else:
+                    v.mul_(mu).add_(p.grad)
+                    p.sub_(v, alpha=lr)
+
+
+def _lars_warmup_trajectory(hip_path, steps=40, lr=0.03, eta=0.01, warm=2, spe=10, size=8):
+    from distributeddeeplearning_amd.callbacks import LearningRateWarmupCallback
+    from distributeddeeplearning_amd.models import resnet18
+    from distributeddeeplearning_amd.ops import functional as ops
+    from distributeddeeplearning_amd.optim import FusedLARS
+
+    g = torch.Generator(device="cpu").manual_seed(11)
+    X = torch.rand((64, 3, 64, 64), generator=g)
+    Y = torch.randint(0, 16, (64,), generator=g).to(DEV)
+    torch.manual_seed(0)
+    model = resnet18(num_classes=16)
+    if hip_path:
+        _hip().reset_caches()
+        model = model.to_compute(torch.device(DEV), BF).train()
+        opt = FusedLARS(model.named_parameters(), lr=lr, momentum=0.9, weight_decay=5e-5, trust_coefficient=eta)
+        X = X.to(DEV).to(BF).contiguous(memory_format=CL)
+    else:
+        model = model.to(DEV).train()
+        opt = _RefLARS(model.parameters(), lr=lr, momentum=0.9, weight_decay=5e-5, eta=eta)
+        X = X.to(DEV)
+    # the reference's schedule head (imagenet_keras_horovod.py:211-213): lr/size -> lr over `warm`
+    # epochs, per batch, with Goyal et al.'s momentum correction at every change of the rate
+    cb = LearningRateWarmupCallback(warmup_epochs=warm, steps_per_epoch=spe, size=size)
+    cb.bind(optimizer=opt, steps_per_epoch=spe)
+    cb.on_train_begin()
+    prev = ops.backend()
+    ops.set_backend("auto" if hip_path else "aten")
+    losses, lrs, mus = [], [], []
+    try:
+        for s in range(steps):
+            e, b = divmod(s, spe)
+            if b == 0:
+                cb.on_epoch_begin(e)
+            cb.on_batch_begin(b)
+            lrs.append(opt.param_groups[0]["lr"])
+            mus.append(opt.param_groups[0]["momentum"])
+            i = (s * 32) % 64
+            opt.zero_grad()
+            loss = ops.softmax_cross_entropy(model(X[i:i + 32]), Y[i:i + 32])
+            loss.backward()
+            opt.step()
+            cb.on_batch_end(b)
+            losses.append(float(loss.detach()))
+    finally:
+        ops.set_backend(prev)
+    return losses, lrs, mus
+
+
+def test_lars_with_warmup_and_momentum_correction_trajectory_hip_bf16_vs_fp32():
+    """BASELINE config 4's recipe end to end: 40 ResNet-18 steps with HIP-bf16
+    FusedLARS + LearningRateWarmupCallback (8 simulated ranks: 0.03/8 -> 0.03 over 20 steps, momentum
+    corrected at every change) against an fp32 PyTorch implementation of the same rule under the same
+    schedule.  fp32 reference on CPU (tuned there): 2.801 2.841 2.766 ... 0.192 0.182 0.154."""
+    ref, lr_r, mu_r = _lars_warmup_trajectory(False)
+    hip, lr_h, mu_h = _lars_warmup_trajectory(True)
+    print("lars fp32:", [round(v, 3) for v in ref])
+    print("lars hip :", [round(v, 3) for v in hip])
+    assert lr_r == lr_h and mu_r == mu_h                       # one schedule drove both optimizers
+    assert abs(lr_h[0] - 0.03 / 8 * (1 + 0.1 * 7 / 2)) < 1e-9 and lr_h[19] == pytest.approx(0.03) and lr_h[-1] == pytest.approx(0.03)
+    assert all(m > 0.9 for m in mu_h[1:20]) and all(m == 0.9 for m in mu_h[20:])   # corrected while the rate moves
+    _compare_trajectories(hip, ref, band=0.15, final_tol=0.05)
+
+
 # ---- optimizers: bf16 parameters, fp32 masters, bf16 gradients ------------------------------------
 def _mixed_params(seed=4):
     g = torch.Generator(device=DEV).manual_seed(seed)
