@@ -788,34 +788,67 @@ __global__ void __launch_bounds__(256) avgpool_bwd_kernel(const bf16_t* __restri
 // dlogits[b][n] = (softmax - onehot) * grad_scale, written with row stride ldd (columns N..ldd-1
 // zero-filled so the padded tensor can feed the dense wgrad/dgrad GEMMs directly).
 // ---------------------------------------------------------------------------------------------
+// `go` (device scalar, nullable): upstream gradient of the mean loss, multiplied into the stored
+// gradient - backward recomputes the row statistics instead of keeping a [B, N] buffer alive and
+// scaling it by an elementwise kernel.  `loss_mean` + `ticket` (nullable pair): the block that
+// finishes last sums the per-row losses in a fixed order and stores their mean - no separate
+// reduction launch, bit-reproducible (placement-independent hand-off: agent-scope release by every
+// block before the ticket, agent-scope acquire by the last arriver; the ticket is left at 0).
 __global__ void __launch_bounds__(256) softmax_xent_kernel(const bf16_t* __restrict__ logits, const long long* __restrict__ labels,
                                                           float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits,
-                                                          int B, int N, int ldl, int ldd, float grad_scale) {
+                                                          int B, int N, int ldl, int ldd, float grad_scale,
+                                                          const float* __restrict__ go, float* __restrict__ loss_mean,
+                                                          unsigned* __restrict__ ticket) {
+    __shared__ int last_s;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B) return;
-    const bf16_t* lp = logits + (long long)row * ldl;
-    float mx = -3.0e38f;
-    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, bf2f(lp[n]));
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int n = lane; n < N; n += 64) sum += __expf(bf2f(lp[n]) - mx);
-    sum = wave_sum(sum);
-    const int label = (int)labels[row];
-    const float lse = mx + __logf(sum);
-    if (lane == 0) loss_rows[row] = (label >= 0 && label < N) ? lse - bf2f(lp[label]) : 0.f;
-    if (dlogits) {
-        bf16_t* dp = dlogits + (long long)row * ldd;
-        const float inv = 1.f / sum;
-        for (int n = lane; n < ldd; n += 64) {
-            float g = 0.f;
-            if (n < N) g = (__expf(bf2f(lp[n]) - mx) * inv - (n == label ? 1.f : 0.f)) * grad_scale;
-            dp[n] = f2bf(g);
+    if (row < B) {
+        const bf16_t* lp = logits + (long long)row * ldl;
+        float mx = -3.0e38f;
+        for (int n = lane; n < N; n += 64) mx = fmaxf(mx, bf2f(lp[n]));
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int n = lane; n < N; n += 64) sum += __expf(bf2f(lp[n]) - mx);
+        sum = wave_sum(sum);
+        const int label = (int)labels[row];
+        const float lse = mx + __logf(sum);
+        if (lane == 0 && loss_rows) loss_rows[row] = (label >= 0 && label < N) ? lse - bf2f(lp[label]) : 0.f;
+        if (dlogits) {
+            bf16_t* dp = dlogits + (long long)row * ldd;
+            const float inv = 1.f / sum;
+            const float gs = go ? grad_scale * go[0] : grad_scale;
+            for (int n = lane; n < ldd; n += 64) {
+                float g = 0.f;
+                if (n < N) g = (__expf(bf2f(lp[n]) - mx) * inv - (n == label ? 1.f : 0.f)) * gs;
+                dp[n] = f2bf(g);
+            }
+        }
+    }
+    if (!loss_mean) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (t == gridDim.x - 1) ? 1 : 0;
+        if (last_s) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if (threadIdx.x < 64) {   // one wave, fixed order: lane-strided partial sums, then the butterfly
+        float s = 0.f;
+        for (int r = lane; r < B; r += 64) s += loss_rows[r];
+        s = wave_sum(s);
+        if (lane == 0) {
+            loss_mean[0] = s / (float)B;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
-
-// y[m][n] += bias[n]
 __global__ void __launch_bounds__(256) bias_add_kernel(bf16_t* __restrict__ y, const float* __restrict__ bias, long long nchunks, int cchunks) {
     long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
@@ -829,10 +862,8 @@ __global__ void __launch_bounds__(256) bias_add_kernel(bf16_t* __restrict__ y, c
     }
 }
 
-// column sums of a bf16 [M][ld] matrix (first N columns) into fp32 — dense-layer bias gradient
-// 256 threads = 32 columns x 8 row lanes, four independent accumulators per lane, LDS fold
-// (one thread per column walking all rows took 69 us for the 256 x 1000 head gradient).
-__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ a, float* __restrict__ out, int M, int N, int ld) {
+__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ a, float* __restrict__ out, int M, int N, int ld,
+                                                     int accumulate) {
     __shared__ float red[8][32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + tx;
@@ -853,7 +884,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
         float s = 0.f;
 #pragma unroll
         for (int l = 0; l < 8; ++l) s += red[l][tx];
-        out[n] = s;
+        out[n] = accumulate ? out[n] + s : s;
     }
 }
 
@@ -1240,14 +1271,21 @@ extern "C" int ddl_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, h
     return ddl_launch_status();
 }
 
-extern "C" int ddl_softmax_xent(const void* logits, const void* labels, void* loss_rows, void* dlogits, int B, int N, int ldl,
-                                int ldd, float grad_scale, hipStream_t stream) {
-    CHK(logits && labels && loss_rows && B > 0 && N > 0 && ldl >= N && (!dlogits || ldd >= N), DDL_EINVAL);
+extern "C" int ddl_softmax_xent_ex(const void* logits, const void* labels, void* loss_rows, void* dlogits, int B, int N, int ldl,
+                                   int ldd, float grad_scale, const void* go, void* loss_mean, void* ticket, hipStream_t stream) {
+    CHK(logits && labels && B > 0 && N > 0 && ldl >= N && (!dlogits || ldd >= N), DDL_EINVAL);
+    CHK(loss_rows || dlogits, DDL_EINVAL);
+    CHK(!loss_mean || (ticket && loss_rows), DDL_EINVAL);
     hipLaunchKernelGGL(softmax_xent_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const bf16_t*)logits,
-                       (const long long*)labels, (float*)loss_rows, (bf16_t*)dlogits, B, N, ldl, ldd, grad_scale);
+                       (const long long*)labels, (float*)loss_rows, (bf16_t*)dlogits, B, N, ldl, ldd, grad_scale,
+                       (const float*)go, (float*)loss_mean, (unsigned*)ticket);
     return ddl_launch_status();
 }
-
+extern "C" int ddl_softmax_xent(const void* logits, const void* labels, void* loss_rows, void* dlogits, int B, int N, int ldl,
+                                int ldd, float grad_scale, hipStream_t stream) {
+    CHK(loss_rows, DDL_EINVAL);
+    return ddl_softmax_xent_ex(logits, labels, loss_rows, dlogits, B, N, ldl, ldd, grad_scale, nullptr, nullptr, nullptr, stream);
+}
 extern "C" int ddl_bias_add(void* y, const void* bias, long long M, int N, hipStream_t stream) {
     CHK(y && bias && M > 0 && N > 0 && (N & 7) == 0, DDL_EINVAL);
     CHK(ddl_aligned16(y) && ddl_aligned16(bias), DDL_EALIGN);
@@ -1256,10 +1294,13 @@ extern "C" int ddl_bias_add(void* y, const void* bias, long long M, int N, hipSt
     return ddl_launch_status();
 }
 
-extern "C" int ddl_colsum(const void* a, void* out, int M, int N, int ld, hipStream_t stream) {
+extern "C" int ddl_colsum_ex(const void* a, void* out, int M, int N, int ld, int accumulate, hipStream_t stream) {
     CHK(a && out && M > 0 && N > 0 && ld >= N, DDL_EINVAL);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, (const bf16_t*)a, (float*)out, M, N, ld);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, (const bf16_t*)a, (float*)out, M, N, ld, accumulate);
     return ddl_launch_status();
+}
+extern "C" int ddl_colsum(const void* a, void* out, int M, int N, int ld, hipStream_t stream) {
+    return ddl_colsum_ex(a, out, M, N, ld, 0, stream);
 }
 
 // table entries are 6 x int64 + ... : see WtEntry; `table` is a device pointer prepared by the host

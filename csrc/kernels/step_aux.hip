@@ -1,0 +1,134 @@
+// Small kernels that keep the training step free of framework (ATen) dispatches: every device
+// operation between two optimizer updates is an in-tree kernel (profiles/r3_notes.md, "one code
+// path").  What they replace, per ResNet-50 step: the loader's index draw + two gathers, the stem's
+// filter repack (fill + strided copy) and gradient unpack (strided copy + accumulate), the padding
+// of the head's logit gradient, the BatchNorm step counters' multi-tensor add.
+#include "common.h"
+
+namespace {
+
+// Philox4x32-10, same constants as elementwise.hip (one counter -> 4 x u32)
+__device__ __forceinline__ void px_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ uint32_t px_first(uint64_t counter, uint64_t seed) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        px_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// ---- synthetic loader: index draw + gather of images and labels in ONE launch -------------------
+// state[0] = batches drawn so far (device-side, so that a recorded launch replays with fresh
+// indices), state[1] = arrival ticket.  Sample b of the batch takes pool row
+// philox(seed, state[0] * batch + b) mod pool_size - the reference's random translation index
+// (HorovodPytorch/src/imagenet_pytorch_horovod.py:162-166,177-188), drawn where it is used.
+// Grid (chunks, batch): every block copies one 16-byte-vector chunk of one image.  The block that
+// arrives last (every block has read state[0] by then) advances the counter.
+__global__ void __launch_bounds__(256) pool_gather_kernel(const u32x4* __restrict__ pool, const long long* __restrict__ pool_labels,
+                                                          u32x4* __restrict__ out, long long* __restrict__ out_labels,
+                                                          unsigned long long* __restrict__ state, int pool_size, int batch,
+                                                          long long row_vec, uint64_t seed) {
+    __shared__ unsigned row_s;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        const unsigned long long step = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        row_s = px_first(step * (unsigned long long)batch + (unsigned long long)b, seed) % (unsigned)pool_size;
+    }
+    __syncthreads();
+    const unsigned row = row_s;
+    const long long per = (row_vec + gridDim.x - 1) / gridDim.x;
+    const long long lo = per * blockIdx.x, hi = lo + per < row_vec ? lo + per : row_vec;
+    const u32x4* src = pool + (long long)row * row_vec;
+    u32x4* dst = out + (long long)b * row_vec;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_labels[b] = pool_labels[row];
+    __syncthreads();   // thread 0 read state[0] before this block's arrival is counted
+    if (threadIdx.x == 0) {
+        const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+        const unsigned long long t = __hip_atomic_fetch_add(state + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == total - 1) {
+            __hip_atomic_store(state + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(state, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---- stem filter: [K][7][7][C<=4] (KRSC bf16) -> [K][7][8][4] zero-padded "row of taps" image ----
+__global__ void __launch_bounds__(256) stem_weight_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int K, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;        // one output element
+    if (i >= K * 7 * 8 * 4) return;
+    const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % 7, k = i / (7 * 32);
+    float v = 0.f;
+    if (s < 7 && c < C) v = bf2f(w[((k * 7 + r) * 7 + s) * C + c]);
+    wp[i] = f2bf(v);
+}
+
+// ---- stem filter gradient: fp32 [K][7][8][4] -> [K][7][7][C] (bf16 or fp32), optionally += -------
+template <typename OutT>
+__global__ void __launch_bounds__(256) stem_dw_unpack_kernel(const float* __restrict__ dwp, OutT* __restrict__ dw, int K, int C,
+                                                             int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;        // one gradient element
+    if (i >= K * 7 * 7 * C) return;
+    const int c = i % C, s = (i / C) % 7, r = (i / (C * 7)) % 7, k = i / (C * 49);
+    float v = dwp[((k * 7 + r) * 8 + s) * 4 + c];
+    if (accumulate) v += (float)dw[i];
+    dw[i] = (OutT)v;
+}
+
+// ---- BatchNorm step counters: table of int64 addresses, each += 1 --------------------------------
+__global__ void __launch_bounds__(256) bump_counters_kernel(long long* const* __restrict__ table, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) *table[i] += 1;
+}
+
+}  // namespace
+
+extern "C" int ddl_pool_gather(const void* pool, const void* pool_labels, void* out, void* out_labels, void* state,
+                               int pool_size, int batch, long long row_bytes, unsigned long long seed, hipStream_t stream) {
+    if (!pool || !pool_labels || !out || !out_labels || !state || pool_size <= 0 || batch <= 0 || batch > 65535) return DDL_EINVAL;
+    if (row_bytes <= 0 || (row_bytes & 15) || !ddl_aligned16(pool) || !ddl_aligned16(out)) return DDL_EALIGN;
+    const long long row_vec = row_bytes >> 4;
+    int chunks = (int)((row_vec + 2047) / 2048);          // ~32 KB per block
+    if (chunks < 1) chunks = 1;
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(pool_gather_kernel, dim3(chunks, batch), dim3(256), 0, stream, (const u32x4*)pool,
+                       (const long long*)pool_labels, (u32x4*)out, (long long*)out_labels, (unsigned long long*)state,
+                       pool_size, batch, row_vec, (uint64_t)seed);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_stem_weight_pack(const void* w, void* wp, int K, int C, hipStream_t stream) {
+    if (!w || !wp || K <= 0 || C < 1 || C > 4) return DDL_EINVAL;
+    hipLaunchKernelGGL(stem_weight_pack_kernel, dim3((K * 7 * 8 * 4 + 255) / 256), dim3(256), 0, stream, (const bf16_t*)w,
+                       (bf16_t*)wp, K, C);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_stem_dw_unpack(const void* dwp, void* dw, int K, int C, int out_is_bf16, int accumulate, hipStream_t stream) {
+    if (!dwp || !dw || K <= 0 || C < 1 || C > 4) return DDL_EINVAL;
+    const dim3 grid((K * 49 * C + 255) / 256);
+    if (out_is_bf16) hipLaunchKernelGGL(stem_dw_unpack_kernel<bf16_t>, grid, dim3(256), 0, stream, (const float*)dwp, (bf16_t*)dw, K, C, accumulate);
+    else hipLaunchKernelGGL(stem_dw_unpack_kernel<float>, grid, dim3(256), 0, stream, (const float*)dwp, (float*)dw, K, C, accumulate);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bump_counters(const void* table, int n, hipStream_t stream) {
+    if (!table || n <= 0) return DDL_EINVAL;
+    hipLaunchKernelGGL(bump_counters_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (long long* const*)table, n);
+    return ddl_launch_status();
+}
+
+// K16: zero a gradient arena (one fill dispatch; the reference's optimizer.zero_grad() issues 161)
+extern "C" int ddl_memset_async(void* p, int value, long long bytes, hipStream_t stream) {
+    if (!p || bytes <= 0) return DDL_EINVAL;
+    return hipMemsetAsync(p, value, (size_t)bytes, stream) == hipSuccess ? DDL_OK : DDL_ELAUNCH;
+}

@@ -72,6 +72,20 @@ class DeviceSyntheticLoader:
         self.pool, self.pool_labels = generate_pool(pool_size, height, width, channels,
                                                     n_classes, self.device, dtype, seed)
         self._gen = torch.Generator(device=self.device)
+        # HIP path: the index draw and both gathers are ONE in-tree kernel (ops/kernels.py::pool_gather);
+        # the batch counter lives on the device, the stream key (seed, epoch, rank) travels by value
+        self._hip = False
+        if self.device.type == "cuda":
+            from ..ops import kernels
+
+            self._hip = kernels.enabled() and (self.pool[0].numel() * self.pool.element_size()) % 16 == 0 \
+                and self.batch_size <= 65535
+        if self._hip:
+            self._state = torch.zeros(2, dtype=torch.int64, device=self.device)
+            self._key = self._stream_key()
+
+    def _stream_key(self):
+        return self.seed * 1000003 + self.epoch * 8191 + self.rank
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -85,6 +99,14 @@ class DeviceSyntheticLoader:
 
     def batch(self, index=None):
         """One batch: a device-side gather from the pool (no host sync)."""
+        if self._hip:
+            from ..ops import kernels
+
+            images = torch.empty((self.batch_size,) + tuple(self.pool.shape[1:]), dtype=self.pool.dtype,
+                                 device=self.device)
+            labels = torch.empty((self.batch_size,), dtype=torch.int64, device=self.device)
+            kernels.pool_gather(self.pool, self.pool_labels, images, labels, self._state, self.batch_size, self._key)
+            return images.permute(0, 3, 1, 2), labels
         idx = torch.randint(0, self.pool.shape[0], (self.batch_size,), generator=self._gen,
                             device=self.device)
         images = self.pool.index_select(0, idx).permute(0, 3, 1, 2)  # NHWC storage, NCHW view
@@ -93,5 +115,8 @@ class DeviceSyntheticLoader:
 
     def __iter__(self):
         self._gen.manual_seed(self.seed * 1000003 + self.epoch * 8191 + self.rank)
+        if self._hip:   # a new epoch is a new Philox stream, counted from its first batch
+            self._key = self._stream_key()
+            self._state.zero_()
         for i in range(self.steps):
             yield self.batch(i)

@@ -209,11 +209,31 @@ class ResNet(nn.Module):
         self.feature_dim = cin
         self.chain_blocks = True  # see _trunk
 
+    def _bump_counters(self):
+        """Every BatchNorm's ``num_batches_tracked`` += 1: one in-tree kernel over a table of the
+        counters' addresses on the HIP path (rebuilt when a buffer moved), one multi-tensor add else."""
+        cache = getattr(self, "_nbt_cache", None)
+        if cache is None or cache[0] is not self.bn1.num_batches_tracked:
+            # (module.to() / load_state_dict(assign=True) replace buffer objects: the first one is the witness)
+            counters = [m.num_batches_tracked for m in self.modules() if isinstance(m, BatchNormAct)]
+            table = None
+            if counters[0].is_cuda:
+                from ..ops import kernels
+
+                if kernels.enabled():
+                    table = torch.tensor([c.data_ptr() for c in counters], dtype=torch.int64).to(counters[0].device)
+            cache = self._nbt_cache = (counters[0], counters, table)
+        if cache[2] is not None:
+            from ..ops import kernels
+
+            kernels.bump_counters(cache[2], len(cache[1]))
+            return
+        torch._foreach_add_(cache[1], 1)
+
     def forward(self, x):
         batched = self.training and not _NBT_BATCHED[0]
         if batched:
-            counters = [m.num_batches_tracked for m in self.modules() if isinstance(m, BatchNormAct)]
-            torch._foreach_add_(counters, 1)
+            self._bump_counters()
             _NBT_BATCHED[0] = True
         try:
             if _has_hooks(self.conv1) or _has_hooks(self.bn1):

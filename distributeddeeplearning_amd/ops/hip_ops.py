@@ -930,6 +930,22 @@ class ConvFn(Function):
         return dx, dw, None, None, None
 
 
+def _stem_dw(dy, xp, geom, w, cin, Ho, Wo):
+    """Filter gradient of the stem: split-K GEMM into the padded [K][7][8][4] fp32 image, then one
+    kernel that drops the padding, casts and - in direct mode - accumulates straight into ``w.grad``
+    (the gradient arena; returns None and notifies the exchange), else returns a new tensor."""
+    Kc = w.shape[0]
+    dwp = torch.empty((Kc, 7, 8, 4), dtype=torch.float32, device=dy.device)
+    _wgrad_into(dy, xp, geom, dwp, Kc, 7, 1, 2, 3, 0, Ho, Wo)
+    if _grad_listeners is not None and _DIRECT["on"] and _direct_grad_ok(w) and _krsc_ok(w):
+        K.stem_dw_unpack(dwp, w.grad, Kc, cin, True)
+        _notify(w)
+        return None
+    dw = torch.empty_like(w)
+    K.stem_dw_unpack(dwp, dw, Kc, cin, False)
+    return dw
+
+
 class StemConvFn(Function):
     """7x7 / stride 2 / pad 3 convolution of a 3-channel image (K5).  The image is repacked to a
     W-padded NHWC4 layout so that each filter row is one contiguous 32-element run; the conv
@@ -943,8 +959,8 @@ class StemConvFn(Function):
         Kc = w.shape[0]
         xp = torch.empty((B, H, W + 8, 4), dtype=_BF16, device=x.device)
         K.stem_pack(x, xp)
-        wp = torch.zeros((Kc, 7, 8, 4), dtype=_BF16, device=x.device)
-        wp[:, :, :7, :C] = w.permute(0, 2, 3, 1)
+        wp = torch.empty((Kc, 7, 8, 4), dtype=_BF16, device=x.device)
+        K.stem_weight_pack(w, wp)
         Ho = (H + 6 - 7) // 2 + 1
         Wo = (W + 6 - 7) // 2 + 1
         geom = (B, H, W + 1, 32, H * (W + 8) * 4, (W + 8) * 4, 4, xp.numel())
@@ -970,11 +986,7 @@ class StemConvFn(Function):
         dy = _as_nhwc(dy)
         Kc = w.shape[0]
         Ho, Wo = dy.shape[2], dy.shape[3]
-        dwp = torch.empty((Kc, 7, 8, 4), dtype=torch.float32, device=dy.device)
-        _wgrad_into(dy, xp, ctx.geom, dwp, Kc, 7, 1, 2, 3, 0, Ho, Wo)
-        dw = torch.empty_like(w)
-        dw.copy_(dwp[:, :, :7, :ctx.cin].permute(0, 3, 1, 2))
-        return None, dw, None
+        return None, _stem_dw(dy, xp, ctx.geom, w, ctx.cin, Ho, Wo), None
 
 
 class StemFn(Function):
@@ -993,8 +1005,8 @@ class StemFn(Function):
         dev = x.device
         xp = torch.empty((B, H, W + 8, 4), dtype=_BF16, device=dev)
         K.stem_pack(x, xp)
-        wp = torch.zeros((Kc, 7, 8, 4), dtype=_BF16, device=dev)
-        wp[:, :, :7, :C] = w.permute(0, 2, 3, 1)
+        wp = torch.empty((Kc, 7, 8, 4), dtype=_BF16, device=dev)
+        K.stem_weight_pack(w, wp)
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         geom = (B, H, W + 1, 32, H * (W + 8) * 4, (W + 8) * 4, 4, xp.numel())
         M = B * Ho * Wo
@@ -1052,10 +1064,7 @@ class StemFn(Function):
         if direct:
             _notify(gamma)
             _notify(beta)
-        dwp = torch.empty((Kc, 7, 8, 4), dtype=torch.float32, device=dev)
-        _wgrad_into(dy, xp, ctx.geom, dwp, Kc, 7, 1, 2, 3, 0, Ho, Wo)
-        dw = torch.empty_like(w)
-        dw.copy_(dwp[:, :, :7, :ctx.cin].permute(0, 3, 1, 2))
+        dw = _stem_dw(dy, xp, ctx.geom, w, ctx.cin, Ho, Wo)
         return None, dw, dg, db, None, None, None, None
 
 
@@ -1537,34 +1546,49 @@ class LinearFn(Function):
         if bias is not None:
             K.bias_add_(y, bias, B, N)
         ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
+        ctx.bias = bias   # a parameter (leaf): a plain reference is safe
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        bias = ctx.bias
         B, C = x.shape
         N = w.shape[0]
         npad = (N + 31) // 32 * 32
-        dy = dy.contiguous()
-        if npad != N:
+        if dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) == npad and dy.dtype == _BF16 and \
+                _XENT["padded"] == (dy.data_ptr(), B, npad):
+            # the loss hands over its gradient inside a zero-padded [B, npad] buffer: no pad pass
+            dyp = torch.as_strided(dy, (B, npad), (npad, 1))
+            _XENT["padded"] = None
+        elif npad != N:
+            dy = dy.contiguous()
             dyp = torch.zeros((B, npad), dtype=_BF16, device=dy.device)
             dyp[:, :N] = dy
         else:
-            dyp = dy
+            dyp = dy.contiguous()
         dx = dw = db = None
         gy = (B, 1, 1, npad, npad, npad, npad, dyp.numel())
         if ctx.needs_input_grad[0]:
             wt, wrows = _dgrad_w(w)
             dx = torch.empty((B, C), dtype=_BF16, device=dy.device)
             K.conv_igemm(dyp, gy, wt, dx, C, 1, 1, 1, 0, 0, 1, 1, 1, wt_rows=wrows)
+        direct = _grad_listeners is not None and _DIRECT["on"]
         if ctx.needs_input_grad[1]:
             gx = (B, 1, 1, C, C, C, C, x.numel())
-            dw = _wgrad_into(dyp, x, gx, torch.empty_like(w), npad, 1, 1, 1, 0, 0, 1, 1,
-                             n_valid=N * C)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty(N, dtype=torch.float32, device=dy.device)
-            K.colsum(dy, db, B, N, N)
+            if direct and _direct_grad_ok(w) and w.is_contiguous():
+                _wgrad_into(dyp, x, gx, w.grad, npad, 1, 1, 1, 0, 0, 1, 1, n_valid=N * C, accumulate=True)
+                _notify(w)
+            else:
+                dw = _wgrad_into(dyp, x, gx, torch.empty_like(w), npad, 1, 1, 1, 0, 0, 1, 1,
+                                 n_valid=N * C)
+        if bias is not None and ctx.needs_input_grad[2]:
+            if direct and _direct_grad_ok(bias) and bias.grad.dtype == torch.float32:
+                K.colsum(dyp, bias.grad, B, N, npad, accumulate=True)
+                _notify(bias)
+            else:
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
+                K.colsum(dyp, db, B, N, npad)
         return dx, dw, db
 
 
@@ -1575,23 +1599,48 @@ def linear(x, weight, bias):
 # ----------------------------------------------------------------------------------------------
 # loss
 # ----------------------------------------------------------------------------------------------
+_XENT = {"ticket": None, "padded": None}
+
+
+def _xent_ticket(device):
+    t = _XENT["ticket"]
+    if t is None or t.device != device:
+        t = _XENT["ticket"] = torch.zeros(4, dtype=torch.int32, device=device)
+    return t
+
+
 class SoftmaxCrossEntropyFn(Function):
+    """``F.cross_entropy`` (mean) of the reference (``imagenet_pytorch_horovod.py:340``) in two
+    launches per step: forward = row losses and their mean (the last block reduces, fixed order);
+    backward = the gradient, recomputed from the logits with the upstream scalar read on the
+    device, written into a zero-padded buffer the dense head consumes without a pad pass."""
+
     @staticmethod
     def forward(ctx, logits, target):
         logits = logits.contiguous()
         if logits.dtype != _BF16:
             logits = logits.to(_BF16)
+        target = target.contiguous()
         B, N = logits.shape
-        loss_rows = torch.empty(B, dtype=torch.float32, device=logits.device)
-        dlogits = torch.empty((B, N), dtype=_BF16, device=logits.device)
-        K.softmax_xent(logits, target.contiguous(), loss_rows, dlogits, B, N, N, N, 1.0 / B)
-        ctx.save_for_backward(dlogits)
-        return loss_rows.mean()
+        out = torch.empty(B + 1, dtype=torch.float32, device=logits.device)   # row losses, then their mean
+        K.softmax_xent(logits, target, out, None, B, N, N, N, 1.0 / B,
+                       loss_mean=out.data_ptr() + 4 * B, ticket=_xent_ticket(logits.device))
+        ctx.save_for_backward(logits, target)
+        return out[B]
 
     @staticmethod
     def backward(ctx, go):
-        (dlogits,) = ctx.saved_tensors
-        return dlogits * go.to(dlogits.dtype), None
+        logits, target = ctx.saved_tensors
+        B, N = logits.shape
+        npad = (N + 31) // 32 * 32
+        if go.dtype != torch.float32 or not go.is_cuda:
+            go = go.to(device=logits.device, dtype=torch.float32)
+        buf = torch.empty((B, npad), dtype=_BF16, device=logits.device)
+        K.softmax_xent(logits, target, None, buf, B, N, N, npad, 1.0 / B, go=go)
+        # columns N..npad of the rows are zeros: LinearFn.backward recognises the buffer by address and
+        # shape and reads it whole (valid for this backward pass only)
+        _XENT["padded"] = (buf.data_ptr(), B, npad)
+        return (buf[:, :N] if npad != N else buf), None
 
 
 def softmax_cross_entropy(logits, target):

@@ -57,7 +57,7 @@ def stream() -> ctypes.c_void_p:
 # through ~30 freshly built c_int / c_void_p objects per call (6.6 us -> 2.7 us per launch on the
 # host, measured): the host has to stay ahead of ~50 us kernels in the late layers' backward.
 _SIG = {"p": ctypes.c_void_p, "i": ctypes.c_int, "q": ctypes.c_longlong, "f": ctypes.c_float,
-        "u": ctypes.c_uint}
+        "u": ctypes.c_uint, "Q": ctypes.c_ulonglong}
 _bound = {}
 
 
@@ -457,10 +457,14 @@ def avgpool_bwd(dy, dx, B, HW, C):
     check(lib().ddl_avgpool_bwd(ptr(dy), ptr(dx), _i32(B), _i32(HW), _i32(C), stream()), "avgpool_bwd")
 
 
-def softmax_xent(logits, labels, loss_rows, dlogits, B, N, ldl, ldd, grad_scale):
-    check(lib().ddl_softmax_xent(ptr(logits), ptr(labels), ptr(loss_rows), ptr(dlogits), _i32(B),
-                                 _i32(N), _i32(ldl), _i32(ldd), _f32(grad_scale), stream()),
-          "softmax_xent")
+def softmax_xent(logits, labels, loss_rows, dlogits, B, N, ldl, ldd, grad_scale, go=None, loss_mean=None,
+                 ticket=None):
+    """K13.  ``loss_rows`` and/or ``dlogits`` may be None (loss only / gradient only); ``go``: device
+    scalar multiplied into the gradient; ``loss_mean`` + ``ticket``: the last block stores the mean
+    of the row losses (fixed order) - no separate reduction launch."""
+    f = _fn("ddl_softmax_xent_ex", "pppp iiii f ppp p")
+    check(f(logits.data_ptr(), labels.data_ptr(), _p(loss_rows), _p(dlogits), B, N, ldl, ldd, grad_scale,
+            _p(go), _p(loss_mean), _p(ticket), _raw_stream()), "softmax_xent")
 
 
 def label_rank(logits, labels):
@@ -478,8 +482,40 @@ def bias_add_(y, bias, M, N):
     check(lib().ddl_bias_add(ptr(y), ptr(bias), _i64(M), _i32(N), stream()), "bias_add")
 
 
-def colsum(a, out, M, N, ld):
-    check(lib().ddl_colsum(ptr(a), ptr(out), _i32(M), _i32(N), _i32(ld), stream()), "colsum")
+def colsum(a, out, M, N, ld, accumulate=False):
+    f = _fn("ddl_colsum_ex", "pp iiii p")
+    check(f(a.data_ptr(), out.data_ptr(), M, N, ld, 1 if accumulate else 0, _raw_stream()), "colsum")
+
+
+# ---- step-side helpers (csrc/kernels/step_aux.hip): no framework dispatch inside the training step
+def pool_gather(pool, pool_labels, out, out_labels, state, batch, seed):
+    """Synthetic loader: draw ``batch`` pool rows (Philox of ``seed`` and the device-side batch
+    counter ``state[0]``, which the kernel advances) and gather images + labels, one launch."""
+    row_bytes = pool[0].numel() * pool.element_size()
+    f = _fn("ddl_pool_gather", "ppppp ii q Q p")
+    check(f(pool.data_ptr(), pool_labels.data_ptr(), out.data_ptr(), out_labels.data_ptr(), state.data_ptr(),
+            pool.shape[0], batch, row_bytes, seed & 0xFFFFFFFFFFFFFFFF, _raw_stream()), "pool_gather")
+
+
+def stem_weight_pack(w, wp):
+    f = _fn("ddl_stem_weight_pack", "pp ii p")
+    check(f(w.data_ptr(), wp.data_ptr(), w.shape[0], w.shape[1], _raw_stream()), "stem_weight_pack")
+
+
+def stem_dw_unpack(dwp, dw, K, C, accumulate):
+    f = _fn("ddl_stem_dw_unpack", "pp iiii p")
+    check(f(_p(dwp), dw.data_ptr(), K, C, 1 if dw.dtype == torch.bfloat16 else 0, 1 if accumulate else 0,
+            _raw_stream()), "stem_dw_unpack")
+
+
+def bump_counters(table, n):
+    f = _fn("ddl_bump_counters", "p i p")
+    check(f(table.data_ptr(), n, _raw_stream()), "bump_counters")
+
+
+def memset_async(t, value=0):
+    f = _fn("ddl_memset_async", "p i q p")
+    check(f(t.data_ptr(), value, t.numel() * t.element_size(), _raw_stream()), "memset_async")
 
 
 def weight_flip_transpose(base_src_addr, base_dst_addr, table, nentries, total_blocks):

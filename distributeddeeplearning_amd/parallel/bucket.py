@@ -161,6 +161,18 @@ def arena_options(cfg) -> dict:
             "grad_dtype": torch.float32 if comm in ("fp32", "float32") else None}
 
 
+def _hip_memset(t) -> bool:
+    try:
+        from ..ops import kernels
+
+        if not kernels.enabled():
+            return False
+        kernels.memset_async(t, 0)
+        return True
+    except Exception:  # pragma: no cover - ops layer unavailable
+        return False
+
+
 def _shaped_view(flat: torch.Tensor, seg: Segment, like: torch.Tensor) -> torch.Tensor:
     """View of ``flat[seg]`` with ``like``'s logical shape and dense stride order (so a
     channels-last conv weight keeps KRSC storage inside the arena)."""
@@ -241,7 +253,10 @@ class GradArena:
         return self.grads[dtype][bucket.start: bucket.end]
 
     def zero_(self):
+        """K16: one fill per arena (the reference's ``optimizer.zero_grad()`` :212 issues 161)."""
         for g in self.grads.values():
+            if g.is_cuda and _hip_memset(g):
+                continue
             g.zero_()
 
     def ensure_view(self, p) -> torch.Tensor:

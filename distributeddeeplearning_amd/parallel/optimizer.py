@@ -320,19 +320,33 @@ class _DistributedMixin:
         return out
 
     def _ddl_verify_order_once(self):
+        """First step only: did the buckets COMPLETE in the order they were planned?  (Within a bucket
+        the arrival order of its gradients is irrelevant: gamma/beta/weight of one layer arrive in
+        another order than they were registered in, which says nothing about overlap.)"""
         if self._ddl_order_checked:
             return
         self._ddl_order_checked = True
-        planned = [seg.name for st in self._ddl_buckets for seg in st.bucket.segments]
-        pos = {n: i for i, n in enumerate(planned)}
-        seen = [pos[n] for n in self._ddl_order_seen if n in pos]
-        inversions = sum(1 for a, b in zip(seen, seen[1:]) if b < a)
+        where = {}
+        for st in self._ddl_buckets:
+            for seg in st.bucket.segments:
+                where[seg.name] = (str(st.dtype), st.bucket.index, len(st.bucket.segments))
+        left, completed = {}, {}
+        for n in self._ddl_order_seen:
+            if n not in where:
+                continue
+            dt, bi, cnt = where[n]
+            left[(dt, bi)] = left.get((dt, bi), cnt) - 1
+            if left[(dt, bi)] == 0:
+                completed.setdefault(dt, []).append(bi)
+        inversions = sum(1 for seq in completed.values() for a, b in zip(seq, seq[1:]) if b < a)
+        nb = sum(len(v) for v in completed.values())
         self._ddl_order_inversions = inversions
-        if _b.engine_config().debug and inversions > max(len(seen) // 4, 1):
+        self._ddl_buckets_completed = nb
+        if _b.engine_config().debug and inversions > 0:
             import warnings
 
-            warnings.warn("gradient arrival order differs from the static bucket plan in %d of "
-                          "%d places; overlap will be reduced" % (inversions, len(seen)))
+            warnings.warn("gradient buckets completed out of plan order in %d of %d places (%s); overlap "
+                          "with backward will be reduced" % (inversions, nb, completed))
         self._ddl_order_seen = []
 
     # -- replica check ----------------------------------------------------------------------

@@ -114,11 +114,11 @@ hvd.init()
 c = hvd.comm()
 dev = torch.device("cuda", 0)
 torch.manual_seed(3)
-m = resnet152(num_classes=100, zero_init_residual=True).to_compute(dev, torch.bfloat16).train()
+m = resnet152(num_classes=128, zero_init_residual=True).to_compute(dev, torch.bfloat16).train()
 opt = hvd.DistributedOptimizer(FusedSGD(m.named_parameters(), lr=0.02, momentum=0.9),
                                named_parameters=m.named_parameters())
 x = torch.rand(8, 3, 224, 224, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-y = torch.randint(0, 100, (8,), device=dev)
+y = torch.randint(0, 128, (8,), device=dev)
 before = c.launch_counts()["rccl"]
 losses = []
 for it in range(4):
@@ -147,7 +147,7 @@ hvd.shutdown()
     assert met["comm_exposed_ms"] is not None and 0 <= met["comm_exposed_ms"] < 5.0, met
     assert len(met["bucket_ms"]) == rec["buckets"] and all(v >= 0 for v in met["bucket_ms"].values()), met
     assert rec["selftest"] and "rccl" in rec["selftest"]["algos"]
-    assert rec["inversions"] is not None and rec["inversions"] <= 467 // 4    # arrival order ~ the static plan
+    assert rec["inversions"] == 0    # every bucket completed in plan order: the exchange overlaps backward as planned
 
 
 def test_bucket_is_complete_when_its_collective_runs():
