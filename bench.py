@@ -68,6 +68,10 @@ def parse_args(argv=None):
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--stall-watch", type=float, default=0.0, metavar="SECONDS",
                     help="diagnostic: dump every thread's stack to stderr when one step takes longer than this")
+    ap.add_argument("--tape", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step from the native launch tape after the first warm-up steps "
+                         "(training/tape.py: same kernels, arguments, streams and order as the eager step; "
+                         "auto = one rank, --warmup >= 3)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one HIP graph after the first warm-up steps "
                          "(training/graph.py); needs --warmup >= 2")
@@ -116,7 +120,20 @@ def main(argv=None):
                                    warmup=min(3, args.warmup - 1),
                                    allow_collectives=os.environ.get("DDL_GRAPH_COLLECTIVES", "0") == "1")
 
+    taped = None
+    want_tape = args.tape == "on" or (args.tape == "auto" and world == 1 and hvd.comm() is None)
+    if want_tape and use_cuda and graphed is None and args.warmup >= 3 and ops.backend() != "aten":
+        from distributeddeeplearning_amd.training.tape import TapedTrainStep
+
+        # eager steps first (lazy initialisation), the recording (a real step, slow: it allocates its
+        # private pool) inside the warm-up, replays from then on
+        taped = TapedTrainStep(model, opt, ops.softmax_cross_entropy, loader=loader,
+                               warmup=min(3, args.warmup - 2),
+                               allow_collectives=os.environ.get("DDL_TAPE_COLLECTIVES", "0") == "1")
+
     def one_step():
+        if taped is not None:
+            return taped()
         images, labels = loader.batch()
         if graphed is not None:
             return graphed(images, labels)
@@ -202,6 +219,10 @@ def main(argv=None):
             "final_loss": round(final_loss, 4),
             "ops_backend": "hip" if (use_cuda and ops.backend() != "aten") else "aten",
             "hip_graph": bool(graphed is not None and graphed.graphed),
+            # launch tape: the timed steps were replayed from native code (launches per step) or issued from Python
+            "launch_tape": bool(taped is not None and taped.taped),
+            "tape_launches": taped.launches if (taped is not None and taped.taped) else None,
+            "tape_refused": None if (taped is None or taped.failed is None) else str(taped.failed)[:200],
             "reserved_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1) if use_cuda else 0.0,
             # gradient exchange: which engine carried it, how long the compute stream sat waiting for
             # it per step (HIP events) and the device time of each bucket's collective

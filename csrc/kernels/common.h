@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <stdint.h>
 
+#include "tape.h"
+
 #define DDL_OK 0
 #define DDL_EINVAL (-1)
 #define DDL_EALIGN (-2)

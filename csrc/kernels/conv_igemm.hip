@@ -633,9 +633,9 @@ int launch_cfg2(const IGemmParams& p, hipStream_t stream) {
     static const int extra_lds = getenv("DDL_CONV_EXTRA_LDS") ? atoi(getenv("DDL_CONV_EXTRA_LDS")) : 0;  // occupancy probe
     const bool mask = p.ep_mask || p.ep_maskbits;
     if (p.stats && p.addend && !(p.ep_y && mask)) return DDL_EINVAL;
-#define DDL_LAUNCH(E, A) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, E, A, GLDS, WT>), grid, block, extra_lds, stream, p)
+#define DDL_LAUNCH(E, A) DDL_KLAUNCH((conv_igemm_kernel<BM, BN, BK, E, A, GLDS, WT>), grid, block, extra_lds, stream, p)
     const bool lean = p.ep_maskbits && !p.ep_y2;
-#define DDL_LAUNCH_LEAN(A) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 4, A, GLDS, WT, false, true>), grid, block, extra_lds, stream, p)
+#define DDL_LAUNCH_LEAN(A) DDL_KLAUNCH((conv_igemm_kernel<BM, BN, BK, 4, A, GLDS, WT, false, true>), grid, block, extra_lds, stream, p)
     if (p.ep_y && mask && p.addend) { if (lean) DDL_LAUNCH_LEAN(true); else DDL_LAUNCH(4, true); }
     else if (p.ep_y && mask) { if (lean) DDL_LAUNCH_LEAN(false); else DDL_LAUNCH(4, false); }
     else if (p.ep_y) DDL_LAUNCH(2, false);
@@ -661,8 +661,8 @@ int launch_cfg(const IGemmParams& p, hipStream_t stream) {
     static const int glds = getenv("DDL_CONV_GLDS") ? atoi(getenv("DDL_CONV_GLDS")) : 1;  // tuning knob
     if (p.x2) {   // two-segment reduction: plain store or the EPI-2 epilogue, LDS-DMA only
         dim3 grid(p.tiles_m * p.tiles_n), block(256);
-        if (p.ep_y) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 2, false, true, false, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, 0, false, true, false, true>), grid, block, 0, stream, p);
+        if (p.ep_y) DDL_KLAUNCH((conv_igemm_kernel<BM, BN, BK, 2, false, true, false, true>), grid, block, 0, stream, p);
+        else DDL_KLAUNCH((conv_igemm_kernel<BM, BN, BK, 0, false, true, false, true>), grid, block, 0, stream, p);
         return ddl_launch_status();
     }
     if (p.wt) return launch_cfg2<BM, BN, BK, true, true>(p, stream);   // transposed weight image: LDS-DMA only

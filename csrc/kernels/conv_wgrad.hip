@@ -402,21 +402,21 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
         const bool glds = glds_env == 2 ? (!one || (p.K >= 128 && p.C >= 128)) : (glds_env > 0 || (glds_env < 0 && !one));   // 2: also the wide 1x1 GEMMs (the isolated optimum)
         const bool bk64 = glds && (bk_env == 64 || (bk_env == 0 && one));
         if (bk64) {
-            if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true, true, 64>), grid, block, 0, stream, p);
-            else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true, true, 64>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false, true, 64>), grid, block, 0, stream, p);
+            if (p.simple) DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, true, true, true, 64>), grid, block, 0, stream, p);
+            else if (p.C % BNw == 0) DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, false, true, true, 64>), grid, block, 0, stream, p);
+            else DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, false, false, true, 64>), grid, block, 0, stream, p);
             return ddl_launch_status();
         }
         if (glds) {
-            if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true, true>), grid, block, 0, stream, p);
-            else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true, true>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false, true>), grid, block, 0, stream, p);
+            if (p.simple) DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, true, true, true>), grid, block, 0, stream, p);
+            else if (p.C % BNw == 0) DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, false, true, true>), grid, block, 0, stream, p);
+            else DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, false, false, true>), grid, block, 0, stream, p);
             return ddl_launch_status();
         }
     }
-    if (p.simple) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, true, true, false>), grid, block, 0, stream, p);
-    else if (p.C % BNw == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<BMw, BNw, false, false, false>), grid, block, 0, stream, p);
+    if (p.simple) DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, true, true, false>), grid, block, 0, stream, p);
+    else if (p.C % BNw == 0) DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, false, true, false>), grid, block, 0, stream, p);
+    else DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, false, false, false>), grid, block, 0, stream, p);
     return ddl_launch_status();
 }
 
@@ -511,7 +511,7 @@ extern "C" int ddl_splitk_reduce(const void* partial, void* out, long long n, in
     const long long n4 = n / 4;
     const int sl = splits >= 64 ? 16 : (splits >= 8 ? 4 : 1);
     dim3 grid((unsigned)((n4 + 256 / sl - 1) / (256 / sl))), block(256);
-#define RL3(T, A, S) hipLaunchKernelGGL((splitk_reduce_kernel<T, A, S>), grid, block, 0, stream, (const float*)partial, (T*)out, n, splits, slab)
+#define RL3(T, A, S) DDL_KLAUNCH((splitk_reduce_kernel<T, A, S>), grid, block, 0, stream, (const float*)partial, (T*)out, n, splits, slab)
 #define RL(T, A) do { if (sl == 16) RL3(T, A, 16); else if (sl == 4) RL3(T, A, 4); else RL3(T, A, 1); } while (0)
     if (out_is_bf16) { if (accumulate) RL(bf16_t, true); else RL(bf16_t, false); }
     else { if (accumulate) RL(float, true); else RL(float, false); }
@@ -530,7 +530,7 @@ extern "C" int ddl_splitk_reduce_lin(const void* partial, void* out, long long n
     const long long n4 = n / 4;
     const int sl = splits >= 64 ? 16 : (splits >= 8 ? 4 : 1);
     dim3 grid((unsigned)((n4 + 256 / sl - 1) / (256 / sl))), block(256);
-#define RL3(TT, A, S) hipLaunchKernelGGL((splitk_reduce_lin_kernel<TT, A, S, false>), grid, block, 0, stream, (const float*)partial, (TT*)out, n, splits, slab, \
+#define RL3(TT, A, S) DDL_KLAUNCH((splitk_reduce_lin_kernel<TT, A, S, false>), grid, block, 0, stream, (const float*)partial, (TT*)out, n, splits, slab, \
                                         (const float*)coef, C, (const bf16_t*)T, (const float*)colz, row_len, (const float*)mean, 0.f)
 #define RL(TT, A) do { if (sl == 16) RL3(TT, A, 16); else if (sl == 4) RL3(TT, A, 4); else RL3(TT, A, 1); } while (0)
     if (out_is_bf16) { if (accumulate) RL(bf16_t, true); else RL(bf16_t, false); }
@@ -548,7 +548,7 @@ extern "C" int ddl_splitk_reduce_centered(const void* partial, void* out, int C,
     const long long n = (long long)C * C, n4 = n / 4;
     const int sl = splits >= 64 ? 16 : (splits >= 8 ? 4 : 1);
     dim3 grid((unsigned)((n4 + 256 / sl - 1) / (256 / sl))), block(256);
-#define RC(S) hipLaunchKernelGGL((splitk_reduce_lin_kernel<bf16_t, false, S, true>), grid, block, 0, stream, (const float*)partial, (bf16_t*)out, n, splits, n, \
+#define RC(S) DDL_KLAUNCH((splitk_reduce_lin_kernel<bf16_t, false, S, true>), grid, block, 0, stream, (const float*)partial, (bf16_t*)out, n, splits, n, \
                                  (const float*)nullptr, C, (const bf16_t*)nullptr, (const float*)colz, C, (const float*)nullptr, 1.0f / (float)M)
     if (sl == 16) RC(16); else if (sl == 4) RC(4); else RC(1);
 #undef RC

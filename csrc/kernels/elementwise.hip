@@ -74,10 +74,10 @@ extern "C" int ddl_philox_uniform(void* out, long long n, int kind, uint64_t see
     if (n == 0) return DDL_OK;
     if (kind == 0) {
         int grid = ddl_stream_grid((n + 7) / 8, 256);
-        hipLaunchKernelGGL(philox_uniform_bf16_kernel, dim3(grid), dim3(256), 0, stream, (bf16_t*)out, n, seed);
+        DDL_KLAUNCH(philox_uniform_bf16_kernel, dim3(grid), dim3(256), 0, stream, (bf16_t*)out, n, seed);
     } else if (kind == 1) {
         int grid = ddl_stream_grid((n + 3) / 4, 256);
-        hipLaunchKernelGGL(philox_uniform_f32_kernel, dim3(grid), dim3(256), 0, stream, (float*)out, n, seed);
+        DDL_KLAUNCH(philox_uniform_f32_kernel, dim3(grid), dim3(256), 0, stream, (float*)out, n, seed);
     } else {
         return DDL_EINVAL;
     }
@@ -86,7 +86,7 @@ extern "C" int ddl_philox_uniform(void* out, long long n, int kind, uint64_t see
 extern "C" int ddl_philox_labels(void* out, long long n, int n_classes, uint64_t seed, hipStream_t stream) {
     if (n < 0 || !out || n_classes <= 0) return DDL_EINVAL;
     if (n == 0) return DDL_OK;
-    hipLaunchKernelGGL(philox_labels_kernel, dim3(ddl_stream_grid(n, 256)), dim3(256), 0, stream,
+    DDL_KLAUNCH(philox_labels_kernel, dim3(ddl_stream_grid(n, 256)), dim3(256), 0, stream,
                        (long long*)out, n, n_classes, seed);
     return ddl_launch_status();
 }
@@ -151,7 +151,7 @@ extern "C" int ddl_fused_sgd_ex(void* w, const void* g, void* v, void* lowp, lon
     if (n == 0) return DDL_OK;
     if (!ddl_aligned16(w) || !ddl_aligned16(g) || !ddl_aligned16(v) || (lowp && !ddl_aligned16(lowp))) return DDL_EALIGN;
     dim3 grid(ddl_stream_grid((n + 7) / 8, 256)), block(256);
-#define LAUNCH(GB, LP) hipLaunchKernelGGL((fused_sgd_kernel<GB, LP>), grid, block, 0, stream, (float*)w, g, (float*)v, (bf16_t*)lowp, n, lr, mu, wd, nesterov, (const float*)lr_scale)
+#define LAUNCH(GB, LP) DDL_KLAUNCH((fused_sgd_kernel<GB, LP>), grid, block, 0, stream, (float*)w, g, (float*)v, (bf16_t*)lowp, n, lr, mu, wd, nesterov, (const float*)lr_scale)
     if (grad_is_bf16) { if (lowp) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (lowp) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -241,12 +241,13 @@ extern "C" int ddl_segmented_sqnorms(const void* w, const void* g, int grad_is_b
                                      const void* seg_end, int nseg, long long n, void* out, hipStream_t stream) {
     if (!w || !g || !seg_start || !seg_end || !out || nseg <= 0 || n <= 0) return DDL_EINVAL;
     if (hipMemsetAsync(out, 0, sizeof(float) * 2 * nseg, stream) != hipSuccess) return DDL_ELAUNCH;
+    if (ddl::tape::recording()) ddl::tape::push([=]() { (void)hipMemsetAsync(out, 0, sizeof(float) * 2 * nseg, stream); });
     dim3 grid((unsigned)((n + LARS_CHUNK - 1) / LARS_CHUNK)), block(256);
     if (grad_is_bf16)
-        hipLaunchKernelGGL(segmented_sqnorm_kernel<true>, grid, block, 0, stream, (const float*)w, g,
+        DDL_KLAUNCH(segmented_sqnorm_kernel<true>, grid, block, 0, stream, (const float*)w, g,
                            (const long long*)seg_start, (const long long*)seg_end, nseg, n, (float*)out);
     else
-        hipLaunchKernelGGL(segmented_sqnorm_kernel<false>, grid, block, 0, stream, (const float*)w, g,
+        DDL_KLAUNCH(segmented_sqnorm_kernel<false>, grid, block, 0, stream, (const float*)w, g,
                            (const long long*)seg_start, (const long long*)seg_end, nseg, n, (float*)out);
     return ddl_launch_status();
 }
@@ -256,7 +257,7 @@ extern "C" int ddl_fused_lars_ex(void* w, const void* g, void* v, void* lowp, co
                                  float wd, const void* lr_scale, hipStream_t stream) {
     if (!w || !g || !v || !ratio || !seg_start || !seg_end || nseg <= 0 || n <= 0) return DDL_EINVAL;
     dim3 grid((unsigned)((n + LARS_CHUNK - 1) / LARS_CHUNK)), block(256);
-#define LAUNCH(GB, LP) hipLaunchKernelGGL((fused_lars_kernel<GB, LP>), grid, block, 0, stream, (float*)w, g, (float*)v, (bf16_t*)lowp, (const float*)ratio, (const long long*)seg_start, (const long long*)seg_end, nseg, n, lr, mu, wd, (const float*)lr_scale)
+#define LAUNCH(GB, LP) DDL_KLAUNCH((fused_lars_kernel<GB, LP>), grid, block, 0, stream, (float*)w, g, (float*)v, (bf16_t*)lowp, (const float*)ratio, (const long long*)seg_start, (const long long*)seg_end, nseg, n, lr, mu, wd, (const float*)lr_scale)
     if (grad_is_bf16) { if (lowp) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (lowp) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
@@ -296,10 +297,10 @@ extern "C" int ddl_nchw_to_nhwc_norm(const void* in, void* out, long long B, int
     long long npix = B * H * W;
     dim3 grid(ddl_stream_grid(npix, 256)), block(256);
     if (in_kind == 0)
-        hipLaunchKernelGGL(nchw_to_nhwc_norm_kernel<float>, grid, block, 0, stream, (const float*)in, (bf16_t*)out, npix,
+        DDL_KLAUNCH(nchw_to_nhwc_norm_kernel<float>, grid, block, 0, stream, (const float*)in, (bf16_t*)out, npix,
                            H * W, C, in_scale, m[0], m[1], m[2], m[3], r[0], r[1], r[2], r[3]);
     else if (in_kind == 1)
-        hipLaunchKernelGGL(nchw_to_nhwc_norm_kernel<unsigned char>, grid, block, 0, stream, (const unsigned char*)in,
+        DDL_KLAUNCH(nchw_to_nhwc_norm_kernel<unsigned char>, grid, block, 0, stream, (const unsigned char*)in,
                            (bf16_t*)out, npix, H * W, C, in_scale, m[0], m[1], m[2], m[3], r[0], r[1], r[2], r[3]);
     else
         return DDL_EINVAL;
@@ -326,6 +327,11 @@ extern "C" int ddl_stream_wait_stream(void* waiter, void* producer, void* event)
     if (!event) return DDL_EINVAL;
     if (hipEventRecord((hipEvent_t)event, (hipStream_t)producer) != hipSuccess) return DDL_ELAUNCH;
     if (hipStreamWaitEvent((hipStream_t)waiter, (hipEvent_t)event, 0) != hipSuccess) return DDL_ELAUNCH;
+    if (ddl::tape::recording())
+        ddl::tape::push([=]() {
+            (void)hipEventRecord((hipEvent_t)event, (hipStream_t)producer);
+            (void)hipStreamWaitEvent((hipStream_t)waiter, (hipEvent_t)event, 0);
+        });
     return DDL_OK;
 }
 

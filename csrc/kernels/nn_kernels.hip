@@ -1035,7 +1035,7 @@ extern "C" int ddl_bn_stats_partial(const void* y, void* partial, long long M, i
     CHK(y && partial && M > 0 && rows_per_tile > 0 && pow2_chunks_ok(C), DDL_EINVAL);
     CHK(ddl_aligned16(y), DDL_EALIGN);
     int T = (int)((M + rows_per_tile - 1) / rows_per_tile);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(T), dim3(256), 0, stream, (const bf16_t*)y, (float*)partial, M, C, rows_per_tile);
+    DDL_KLAUNCH(bn_stats_partial_kernel, dim3(T), dim3(256), 0, stream, (const bf16_t*)y, (float*)partial, M, C, rows_per_tile);
     return ddl_launch_status();
 }
 
@@ -1058,7 +1058,7 @@ extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long 
     CHK((long long)T * rows_per_tile >= M && (long long)(T - 1) * rows_per_tile < M, DDL_EINVAL);
     CHK((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, DDL_EALIGN);
     if (T <= 512) {
-        hipLaunchKernelGGL(bn_fwd_finalize_direct_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, T, C,
+        DDL_KLAUNCH(bn_fwd_finalize_direct_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, T, C,
                            M, (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
                            (float*)mean, (float*)invstd, (float*)scale, (float*)shift);
         return ddl_launch_status();
@@ -1071,13 +1071,13 @@ extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long 
         a.M = M; a.gamma = (const float*)gamma; a.beta = (const float*)beta; a.rmean = (float*)rmean; a.rvar = (float*)rvar;
         a.momentum = momentum; a.eps = eps; a.mean_out = (float*)mean; a.invstd_out = (float*)invstd;
         a.scale = (float*)scale; a.shift = (float*)shift;
-        hipLaunchKernelGGL((bn_fold_finish_kernel<double, 0>), dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial,
+        DDL_KLAUNCH((bn_fold_finish_kernel<double, 0>), dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial,
                            T, C, P, (double*)workspace, tickets, a);
         return ddl_launch_status();
     }
-    hipLaunchKernelGGL(bn_stats_fold_kernel<double>, dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
+    DDL_KLAUNCH(bn_stats_fold_kernel<double>, dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial, T, C, P,
                        (double*)workspace);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)workspace, P, C, M,
+    DDL_KLAUNCH(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)workspace, P, C, M,
                        (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
                        (float*)mean, (float*)invstd, (float*)scale, (float*)shift);
     return ddl_launch_status();
@@ -1086,7 +1086,7 @@ extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long 
 extern "C" int ddl_bn_eval_coeffs(const void* gamma, const void* beta, const void* rmean, const void* rvar, float eps, int C,
                                   void* scale, void* shift, hipStream_t stream) {
     CHK(gamma && beta && rmean && rvar && scale && shift && C > 0, DDL_EINVAL);
-    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)gamma,
+    DDL_KLAUNCH(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)gamma,
                        (const float*)beta, (const float*)rmean, (const float*)rvar, eps, C, (float*)scale, (float*)shift);
     return ddl_launch_status();
 }
@@ -1103,7 +1103,7 @@ extern "C" int ddl_bn_apply_fwd_ex2(const void* y, const void* scale, const void
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
     const bool nt = M * C * 2 >= nt_threshold_bytes();
     const int rmode = !res ? 0 : (rscale ? 2 : 1);
-#define L2(R, S, N) hipLaunchKernelGGL((bn_apply_fwd_kernel<R, S, N>), grid, block, (S == 2 ? 16 * (size_t)C : 0), stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (const float*)rscale, (const float*)rshift, (bf16_t*)z, (unsigned char*)bits, nchunks, C >> 3)
+#define L2(R, S, N) DDL_KLAUNCH((bn_apply_fwd_kernel<R, S, N>), grid, block, (S == 2 ? 16 * (size_t)C : 0), stream, (const bf16_t*)y, (const float*)scale, (const float*)shift, (const bf16_t*)res, (const float*)rscale, (const float*)rshift, (bf16_t*)z, (unsigned char*)bits, nchunks, C >> 3)
 #define L(R, S) do { if (nt) L2(R, S, true); else L2(R, S, false); } while (0)
 #define LR(R) do { if (rmode == 2) L(R, 2); else if (rmode == 1) L(R, 1); else L(R, 0); } while (0)
     if (relu) LR(true); else LR(false);
@@ -1140,7 +1140,7 @@ extern "C" int ddl_bn_bwd_reduce(const void* dz, const void* y, const void* z, c
     CHK(mask == 0 || (mask == 1 && z) || (mask == 2 && fcoef), DDL_EINVAL);
     CHK(ddl_aligned16(dz) && ddl_aligned16(y) && (!z || ddl_aligned16(z)) && (!fcoef || ddl_aligned16(fcoef)), DDL_EALIGN);
     long long rpb = (M + G - 1) / G;
-#define L(MK) hipLaunchKernelGGL(bn_bwd_reduce_kernel<MK>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (float*)partial, M, C, rpb)
+#define L(MK) DDL_KLAUNCH(bn_bwd_reduce_kernel<MK>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (float*)partial, M, C, rpb)
     if (mask == 1) L(1); else if (mask == 2) L(2); else L(0);
 #undef L
     return ddl_launch_status();
@@ -1160,17 +1160,17 @@ extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long 
             BnFinishArgs a = {};
             a.M = M; a.gamma = (const float*)gamma; a.mean = (const float*)mean; a.invstd = (const float*)invstd;
             a.dgamma = (float*)dgamma; a.dbeta = (float*)dbeta; a.coef = (float*)coef; a.accumulate = accumulate;
-            hipLaunchKernelGGL((bn_fold_finish_kernel<float, 1>), dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial,
+            DDL_KLAUNCH((bn_fold_finish_kernel<float, 1>), dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial,
                                G, C, P, (float*)workspace, tickets + 256, a);
             return ddl_launch_status();
         }
-        hipLaunchKernelGGL(bn_stats_fold_kernel<float>, dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial, G, C,
+        DDL_KLAUNCH(bn_stats_fold_kernel<float>, dim3((C + 15) / 16, P), dim3(256), 0, stream, (const float*)partial, G, C,
                            P, (float*)workspace);
         if (ddl_launch_status() != DDL_OK) return DDL_ELAUNCH;
         partial = workspace;
         G = P;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)partial, G, C, M,
+    DDL_KLAUNCH(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, (const float*)partial, G, C, M,
                        (const float*)gamma, (const float*)mean, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef, accumulate);
     return ddl_launch_status();
 }
@@ -1185,7 +1185,7 @@ extern "C" int ddl_bn_bwd_apply(const void* dz, const void* y, const void* z, co
     long long nchunks = M * (C >> 3);
     dim3 grid(ddl_stream_grid(nchunks, 256)), block(256);
     const bool nt = M * C * 2 >= nt_threshold_bytes();
-#define L2(MK, G, N) hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, G, N>), grid, block, (MK == 2 ? 20 : 12) * (size_t)C, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
+#define L2(MK, G, N) DDL_KLAUNCH((bn_bwd_apply_kernel<MK, G, N>), grid, block, (MK == 2 ? 20 : 12) * (size_t)C, stream, (const bf16_t*)dz, (const bf16_t*)y, (const bf16_t*)z, (const float*)fcoef, (const float*)coef, (bf16_t*)dy, (bf16_t*)gout, nchunks, C >> 3)
 #define L(MK, G) do { if (nt) L2(MK, G, true); else L2(MK, G, false); } while (0)
     if (mask == 1) { if (gout) L(1, true); else L(1, false); }
     else if (mask == 2) { if (gout) L(2, true); else L(2, false); }
@@ -1204,9 +1204,9 @@ static int maxpool_fwd_launch(const void* x, const void* scale, const void* shif
     long long total = (long long)B * Ho * Wo * (C >> 3);
     CHK((long long)B * H * W * (C >> 3) < (1LL << 32), DDL_EINVAL);
     dim3 grid(ddl_stream_grid(total, 256)), block(256);
-    if (scale) hipLaunchKernelGGL(maxpool_fwd_kernel<true>, grid, block, 0, stream, (const bf16_t*)x, (const float*)scale,
+    if (scale) DDL_KLAUNCH(maxpool_fwd_kernel<true>, grid, block, 0, stream, (const bf16_t*)x, (const float*)scale,
                                   (const float*)shift, (bf16_t*)out, (unsigned char*)idx, B, H, W, C, Ho, Wo);
-    else hipLaunchKernelGGL(maxpool_fwd_kernel<false>, grid, block, 0, stream, (const bf16_t*)x, (const float*)nullptr,
+    else DDL_KLAUNCH(maxpool_fwd_kernel<false>, grid, block, 0, stream, (const bf16_t*)x, (const float*)nullptr,
                             (const float*)nullptr, (bf16_t*)out, (unsigned char*)idx, B, H, W, C, Ho, Wo);
     return ddl_launch_status();
 }
@@ -1235,10 +1235,10 @@ extern "C" int ddl_stem_pool_bn_bwd(const void* dpool, const void* idx, const vo
     CHK(M < (1LL << 31), DDL_EINVAL);
     const long long NP = (long long)B * ((H + 1) / 2) * ((W + 1) / 2);   // 2x2 pixel patches
     long long rpb = (NP + G - 1) / G;
-    if (apply) hipLaunchKernelGGL(stem_pool_bn_bwd_kernel<true>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dpool,
+    if (apply) DDL_KLAUNCH(stem_pool_bn_bwd_kernel<true>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dpool,
                                   (const unsigned char*)idx, (const bf16_t*)y, (const float*)fcoef, (const float*)coef,
                                   (float*)nullptr, (bf16_t*)dy, B, H, W, C, Ho, Wo, rpb);
-    else hipLaunchKernelGGL(stem_pool_bn_bwd_kernel<false>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dpool,
+    else DDL_KLAUNCH(stem_pool_bn_bwd_kernel<false>, dim3(G), dim3(256), 0, stream, (const bf16_t*)dpool,
                             (const unsigned char*)idx, (const bf16_t*)y, (const float*)fcoef, (const float*)nullptr,
                             (float*)partial, (bf16_t*)nullptr, B, H, W, C, Ho, Wo, rpb);
     return ddl_launch_status();
@@ -1250,7 +1250,7 @@ extern "C" int ddl_maxpool3x3s2_bwd(const void* dy, const void* idx, void* dx, i
     int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     long long total = (long long)B * H * W * (C >> 3);
     CHK(total < (1LL << 32), DDL_EINVAL);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)dy,
+    DDL_KLAUNCH(maxpool_bwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)dy,
                        (const unsigned char*)idx, (bf16_t*)dx, B, H, W, C, Ho, Wo);
     return ddl_launch_status();
 }
@@ -1259,7 +1259,7 @@ extern "C" int ddl_avgpool_fwd(const void* x, void* out, int B, int HW, int C, h
     CHK(x && out && B > 0 && HW > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
     CHK(ddl_aligned16(x) && ddl_aligned16(out), DDL_EALIGN);
     long long total = (long long)B * (C >> 3);
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, B, HW, C);
+    DDL_KLAUNCH(avgpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, B, HW, C);
     return ddl_launch_status();
 }
 
@@ -1267,7 +1267,7 @@ extern "C" int ddl_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, h
     CHK(dy && dx && B > 0 && HW > 0 && C > 0 && (C & 7) == 0, DDL_EINVAL);
     CHK(ddl_aligned16(dy) && ddl_aligned16(dx), DDL_EALIGN);
     long long total = (long long)B * HW * (C >> 3);
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)dy, (bf16_t*)dx, B, HW, C);
+    DDL_KLAUNCH(avgpool_bwd_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)dy, (bf16_t*)dx, B, HW, C);
     return ddl_launch_status();
 }
 
@@ -1276,7 +1276,7 @@ extern "C" int ddl_softmax_xent_ex(const void* logits, const void* labels, void*
     CHK(logits && labels && B > 0 && N > 0 && ldl >= N && (!dlogits || ldd >= N), DDL_EINVAL);
     CHK(loss_rows || dlogits, DDL_EINVAL);
     CHK(!loss_mean || (ticket && loss_rows), DDL_EINVAL);
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const bf16_t*)logits,
+    DDL_KLAUNCH(softmax_xent_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const bf16_t*)logits,
                        (const long long*)labels, (float*)loss_rows, (bf16_t*)dlogits, B, N, ldl, ldd, grad_scale,
                        (const float*)go, (float*)loss_mean, (unsigned*)ticket);
     return ddl_launch_status();
@@ -1290,13 +1290,13 @@ extern "C" int ddl_bias_add(void* y, const void* bias, long long M, int N, hipSt
     CHK(y && bias && M > 0 && N > 0 && (N & 7) == 0, DDL_EINVAL);
     CHK(ddl_aligned16(y) && ddl_aligned16(bias), DDL_EALIGN);
     long long nchunks = M * (N >> 3);
-    hipLaunchKernelGGL(bias_add_kernel, dim3(ddl_stream_grid(nchunks, 256)), dim3(256), 0, stream, (bf16_t*)y, (const float*)bias, nchunks, N >> 3);
+    DDL_KLAUNCH(bias_add_kernel, dim3(ddl_stream_grid(nchunks, 256)), dim3(256), 0, stream, (bf16_t*)y, (const float*)bias, nchunks, N >> 3);
     return ddl_launch_status();
 }
 
 extern "C" int ddl_colsum_ex(const void* a, void* out, int M, int N, int ld, int accumulate, hipStream_t stream) {
     CHK(a && out && M > 0 && N > 0 && ld >= N, DDL_EINVAL);
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, (const bf16_t*)a, (float*)out, M, N, ld, accumulate);
+    DDL_KLAUNCH(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, stream, (const bf16_t*)a, (float*)out, M, N, ld, accumulate);
     return ddl_launch_status();
 }
 extern "C" int ddl_colsum(const void* a, void* out, int M, int N, int ld, hipStream_t stream) {
@@ -1307,7 +1307,7 @@ extern "C" int ddl_colsum(const void* a, void* out, int M, int N, int ld, hipStr
 extern "C" int ddl_weight_flip_transpose(const void* base_src, void* base_dst, const void* table, int nentries,
                                          int total_blocks, hipStream_t stream) {
     CHK(base_src && base_dst && table && nentries > 0 && total_blocks > 0, DDL_EINVAL);
-    hipLaunchKernelGGL(weight_flip_transpose_kernel, dim3(total_blocks), dim3(256), 0, stream, (const bf16_t*)base_src,
+    DDL_KLAUNCH(weight_flip_transpose_kernel, dim3(total_blocks), dim3(256), 0, stream, (const bf16_t*)base_src,
                        (bf16_t*)base_dst, (const WtEntry*)table, nentries);
     return ddl_launch_status();
 }
@@ -1349,12 +1349,12 @@ extern "C" int ddl_stem_pack(const void* x, void* out, int B, int H, int W, int 
     if (C == 3 && (W & 3) == 0 && xs_c == 1 && xs_w == 3 && xs_h == 3LL * W && xs_b == 3LL * W * H &&
         (reinterpret_cast<uintptr_t>(x) & 7) == 0) {
         const long long rows = (long long)B * H;
-        hipLaunchKernelGGL(stem_pack3_kernel, dim3(ddl_stream_grid(rows * ((W >> 2) + 2), 256)), dim3(256), 0, stream,
+        DDL_KLAUNCH(stem_pack3_kernel, dim3(ddl_stream_grid(rows * ((W >> 2) + 2), 256)), dim3(256), 0, stream,
                            (const bf16_t*)x, (bf16_t*)out, rows, W);
         return ddl_launch_status();
     }
     long long total = (long long)B * H * (W + 8);
-    hipLaunchKernelGGL(stem_pack_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)x,
+    DDL_KLAUNCH(stem_pack_kernel, dim3(ddl_stream_grid(total, 256)), dim3(256), 0, stream, (const bf16_t*)x,
                        (bf16_t*)out, B, H, W, C, xs_b, xs_h, xs_w, xs_c);
     return ddl_launch_status();
 }
@@ -1362,7 +1362,7 @@ extern "C" int ddl_stem_pack(const void* x, void* out, int B, int H, int W, int 
 // rank[row] = number of logits that precede the label's in top-k order; N for an invalid label
 extern "C" int ddl_label_rank(const void* logits, const void* labels, void* rank, int B, int N, int ld, hipStream_t stream) {
     CHK(logits && labels && rank && B > 0 && N > 0 && ld >= N, DDL_EINVAL);
-    hipLaunchKernelGGL(label_rank_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const bf16_t*)logits,
+    DDL_KLAUNCH(label_rank_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, (const bf16_t*)logits,
                        (const long long*)labels, (int*)rank, B, N, ld);
     return ddl_launch_status();
 }
@@ -1372,7 +1372,7 @@ extern "C" int ddl_bn_lin_prep(const void* wt, int ld, const void* coef, int C, 
                                hipStream_t stream) {
     CHK(wt && coef && b1 && a2 && bias && C > 0 && C <= 2048 && (C & 7) == 0 && rows > 0 && ld >= C && (ld & 7) == 0, DDL_EINVAL);
     CHK(ddl_aligned16(wt) && ddl_aligned16(coef) && ddl_aligned16(b1) && ddl_aligned16(a2), DDL_EALIGN);
-    hipLaunchKernelGGL(bn_lin_prep_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)wt, ld, (const float*)coef, C,
+    DDL_KLAUNCH(bn_lin_prep_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)wt, ld, (const float*)coef, C,
                        (bf16_t*)b1, (bf16_t*)a2, (float*)bias);
     return ddl_launch_status();
 }
@@ -1380,7 +1380,7 @@ extern "C" int ddl_bn_lin_prep(const void* wt, int ld, const void* coef, int C, 
 // out[2][C] = sum over the T rows of partial[T][2][C] (one slice of the fold kernel)
 extern "C" int ddl_bn_colsum_fold(const void* partial, int T, int C, void* out, hipStream_t stream) {
     CHK(partial && out && T > 0 && C > 0, DDL_EINVAL);
-    hipLaunchKernelGGL((bn_stats_fold_kernel<float>), dim3((C + 15) / 16, 1), dim3(256), 0, stream, (const float*)partial, T, C, 1,
+    DDL_KLAUNCH((bn_stats_fold_kernel<float>), dim3((C + 15) / 16, 1), dim3(256), 0, stream, (const float*)partial, T, C, 1,
                        (float*)out);
     return ddl_launch_status();
 }

@@ -100,7 +100,7 @@ extern "C" int ddl_pool_gather(const void* pool, const void* pool_labels, void* 
     int chunks = (int)((row_vec + 2047) / 2048);          // ~32 KB per block
     if (chunks < 1) chunks = 1;
     if (chunks > 64) chunks = 64;
-    hipLaunchKernelGGL(pool_gather_kernel, dim3(chunks, batch), dim3(256), 0, stream, (const u32x4*)pool,
+    DDL_KLAUNCH(pool_gather_kernel, dim3(chunks, batch), dim3(256), 0, stream, (const u32x4*)pool,
                        (const long long*)pool_labels, (u32x4*)out, (long long*)out_labels, (unsigned long long*)state,
                        pool_size, batch, row_vec, (uint64_t)seed);
     return ddl_launch_status();
@@ -108,7 +108,7 @@ extern "C" int ddl_pool_gather(const void* pool, const void* pool_labels, void* 
 
 extern "C" int ddl_stem_weight_pack(const void* w, void* wp, int K, int C, hipStream_t stream) {
     if (!w || !wp || K <= 0 || C < 1 || C > 4) return DDL_EINVAL;
-    hipLaunchKernelGGL(stem_weight_pack_kernel, dim3((K * 7 * 8 * 4 + 255) / 256), dim3(256), 0, stream, (const bf16_t*)w,
+    DDL_KLAUNCH(stem_weight_pack_kernel, dim3((K * 7 * 8 * 4 + 255) / 256), dim3(256), 0, stream, (const bf16_t*)w,
                        (bf16_t*)wp, K, C);
     return ddl_launch_status();
 }
@@ -116,19 +116,21 @@ extern "C" int ddl_stem_weight_pack(const void* w, void* wp, int K, int C, hipSt
 extern "C" int ddl_stem_dw_unpack(const void* dwp, void* dw, int K, int C, int out_is_bf16, int accumulate, hipStream_t stream) {
     if (!dwp || !dw || K <= 0 || C < 1 || C > 4) return DDL_EINVAL;
     const dim3 grid((K * 49 * C + 255) / 256);
-    if (out_is_bf16) hipLaunchKernelGGL(stem_dw_unpack_kernel<bf16_t>, grid, dim3(256), 0, stream, (const float*)dwp, (bf16_t*)dw, K, C, accumulate);
-    else hipLaunchKernelGGL(stem_dw_unpack_kernel<float>, grid, dim3(256), 0, stream, (const float*)dwp, (float*)dw, K, C, accumulate);
+    if (out_is_bf16) DDL_KLAUNCH(stem_dw_unpack_kernel<bf16_t>, grid, dim3(256), 0, stream, (const float*)dwp, (bf16_t*)dw, K, C, accumulate);
+    else DDL_KLAUNCH(stem_dw_unpack_kernel<float>, grid, dim3(256), 0, stream, (const float*)dwp, (float*)dw, K, C, accumulate);
     return ddl_launch_status();
 }
 
 extern "C" int ddl_bump_counters(const void* table, int n, hipStream_t stream) {
     if (!table || n <= 0) return DDL_EINVAL;
-    hipLaunchKernelGGL(bump_counters_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (long long* const*)table, n);
+    DDL_KLAUNCH(bump_counters_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (long long* const*)table, n);
     return ddl_launch_status();
 }
 
 // K16: zero a gradient arena (one fill dispatch; the reference's optimizer.zero_grad() issues 161)
 extern "C" int ddl_memset_async(void* p, int value, long long bytes, hipStream_t stream) {
     if (!p || bytes <= 0) return DDL_EINVAL;
-    return hipMemsetAsync(p, value, (size_t)bytes, stream) == hipSuccess ? DDL_OK : DDL_ELAUNCH;
+    if (hipMemsetAsync(p, value, (size_t)bytes, stream) != hipSuccess) return DDL_ELAUNCH;
+    if (ddl::tape::recording()) ddl::tape::push([=]() { (void)hipMemsetAsync(p, value, (size_t)bytes, stream); });
+    return DDL_OK;
 }

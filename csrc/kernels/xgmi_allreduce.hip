@@ -237,7 +237,7 @@ extern "C" int ddl_pack_scale_cast(const void* table, int nentries, void* flat, 
                                    float scale, int unpack, hipStream_t stream) {
     if (!table || !flat || nentries <= 0) return DDL_EINVAL;
     dim3 grid(64, nentries < 256 ? nentries : 256), block(256);
-#define PK(S, D, U) hipLaunchKernelGGL((pack_kernel<S, D, U>), grid, block, 0, stream, (const PackEntry*)table, nentries, flat, scale)
+#define PK(S, D, U) DDL_KLAUNCH((pack_kernel<S, D, U>), grid, block, 0, stream, (const PackEntry*)table, nentries, flat, scale)
     if (src_is_bf16) {
         if (flat_is_bf16) { if (unpack) PK(bf16_t, bf16_t, true); else PK(bf16_t, bf16_t, false); }
         else { if (unpack) PK(bf16_t, float, true); else PK(bf16_t, float, false); }

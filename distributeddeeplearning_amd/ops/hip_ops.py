@@ -121,13 +121,13 @@ class _WeightTransposes:
             return
         if torch.cuda.is_current_stream_capturing():
             return
-        side = _side_stream(self.dst.device)
-        side.wait_stream(torch.cuda.current_stream(self.dst.device))   # after the optimizer's writes
-        with torch.cuda.stream(side):
+        # raw stream handles and events (no torch stream switch): the calls are recorded by the launch
+        # tape like every kernel launch, and cost a third of the torch objects on the host
+        side = _side_stream(self.dst.device).cuda_stream
+        K.stream_wait_stream(side, K._raw_stream(), _SIDE["event"])   # after the optimizer's writes
+        with K.launch_on(side):
             self._launch()
-            ev = torch.cuda.Event()
-            ev.record(side)
-        self.pending = ev
+        self.pending = side
 
     def get(self, w):
         e = self.entries.get(id(w))
@@ -135,7 +135,7 @@ class _WeightTransposes:
             self._register(w)
             e = self.entries[id(w)]
         if self.pending is not None:   # first use after an asynchronous refresh: order this stream behind it
-            torch.cuda.current_stream().wait_event(self.pending)
+            K.stream_wait_stream(K._raw_stream(), self.pending, _SIDE["event_wt"])
             self.pending = None
         stale = self.dirty or self.done_epoch != self.epoch or e["version"] != w._version
         if not stale and self.captured_epoch != self.epoch and torch.cuda.is_current_stream_capturing():
@@ -457,6 +457,8 @@ def _side_stream(device):
                 st = torch.cuda.ExternalStream(K.create_stream(want), device=device)
         with torch.cuda.device(device):
             _SIDE["event"] = K.create_event()
+            _SIDE["event_wt"] = K.create_event()
+            _SIDE["event_join"] = K.create_event()
         _SIDE["stream"] = st
         _SIDE["ws"] = None
     return st
@@ -467,10 +469,10 @@ def _join_side_stream():
     st = _SIDE["stream"]
     if st is not None and _SIDE["pending"]:
         cur = torch.cuda.current_stream(st.device)
-        cur.wait_stream(st)
+        K.stream_wait_stream(cur.cuda_stream, st.cuda_stream, _SIDE["event_join"])
         main = _SIDE.get("main")
         if main is not None and main != cur:  # the stream backward ran on
-            main.wait_stream(st)
+            K.stream_wait_stream(main.cuda_stream, st.cuda_stream, _SIDE["event_join"])
     _SIDE["pending"] = False
     _SIDE["join_queued"] = False
     if _SIDE["keep"]:

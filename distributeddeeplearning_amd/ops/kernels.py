@@ -49,7 +49,8 @@ def lib():
 
 
 def stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The stream this thread's launchers queue on: torch's current stream unless ``launch_on`` redirects."""
+    return ctypes.c_void_p(_raw_stream())
 
 
 # ---- fast path for the launchers called ~500 times per training step ---------------------------

@@ -136,6 +136,11 @@ class _ArenaOptimizer(Optimizer):
 
             hip_ops.weights_changed()
 
+    def after_replayed_step(self):
+        """Host-side bookkeeping of a step that ran from the launch tape (training/tape.py): the
+        device work was replayed, the Python ``step()`` was not."""
+        self._step += 1
+
     # -- checkpoint surface ----------------------------------------------------------------
     def state_dict(self):
         groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]

@@ -31,6 +31,7 @@ import os
 
 import torch
 
+from ..ops import tape as _tape
 from ..utils import trace as _trace
 from . import backend as _b
 from . import timeline as _tl
@@ -244,6 +245,11 @@ class _DistributedMixin:
         st.launched = True
         if _b.size() == 1 and _b.comm() is None:
             return
+        # the hand-off to the communication engine cannot live on a launch tape: it runs as a live
+        # action, again and in place at every replay of a recorded step (ops/tape.py)
+        _tape.live(lambda: self._ddl_launch_now(st))
+
+    def _ddl_launch_now(self, st):
         name = "grad.%s.bucket%d" % (str(st.dtype).replace("torch.", ""), st.bucket.index)
         _tl.begin(name, "ALLREDUCE")
         _trace.mark("launch " + name)
@@ -261,6 +267,11 @@ class _DistributedMixin:
                 st.needs_scale = True
 
     def _ddl_finish(self, st):
+        if st.work is None:
+            return
+        _tape.live(lambda: self._ddl_finish_now(st))
+
+    def _ddl_finish_now(self, st):
         if st.work is None:
             return
         deadline = _b.engine_config().collective_timeout_s
@@ -302,7 +313,7 @@ class _DistributedMixin:
         for st in self._ddl_buckets:
             self._ddl_finish(st)
         if self._ddl_metrics is not None:
-            self._ddl_metrics.end_step()
+            _tape.live(self._ddl_metrics.end_step)
         self._ddl_verify_order_once()
 
     def comm_metrics(self):
@@ -450,11 +461,17 @@ class _DistributedMixin:
                 self._ddl_finish(st)
                 per_bucket(st.dtype, st.bucket.start, st.bucket.end)
         if self._ddl_metrics is not None:
-            self._ddl_metrics.end_step()
+            _tape.live(self._ddl_metrics.end_step)
         self._ddl_verify_order_once()
         self._ddl_reset_buckets()
         self._ddl_step_count += 1
         return base.end_step()
+
+    def after_replayed_step(self):
+        self._ddl_step_count += 1
+        done = getattr(super(self.__class__, self), "after_replayed_step", None)
+        if done is not None:
+            done()
 
     def zero_grad(self, set_to_none=False):
         """Zero the arenas (one memset per dtype).  Gradients stay views into the arena, so
