@@ -185,6 +185,16 @@ def main(argv=None):
     sync()
     elapsed = time.perf_counter() - t0
 
+    # host cost of issuing ONE step into an empty queue (the loop above runs ahead of the GPU until the
+    # hardware queue pushes back, so its host time says little once the step is GPU-bound)
+    single = []
+    for _ in range(3 if use_cuda else 0):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss = one_step()
+        single.append(time.perf_counter() - t1)
+    sync()
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if use_cuda else "cpu")
     if world > 1:
         t = hvd.allreduce(t, op=hvd.Max, name="bench.elapsed")
@@ -209,6 +219,7 @@ def main(argv=None):
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "host_issue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
+            "host_issue_ms_single_step": round(min(single) * 1e3, 3) if single else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None if vs is None else round(vs, 4),

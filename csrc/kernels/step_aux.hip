@@ -90,7 +90,32 @@ __global__ void __launch_bounds__(256) bump_counters_kernel(long long* const* __
     if (i < n) *table[i] += 1;
 }
 
+// ---- every second row and column of an NHWC tensor (input of a stride-2 1x1 projection) ---------
+__global__ void __launch_bounds__(256) subsample2_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out, int H, int W, int Ho,
+                                                         int Wo, int cvec, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one 16-byte vector of the output
+    if (i >= total) return;
+    const int c = (int)(i % cvec);
+    long long p = i / cvec;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const long long b = p / Ho;
+    out[i] = x[((b * H + 2 * ho) * W + 2 * wo) * cvec + c];
+}
+
 }  // namespace
+
+extern "C" int ddl_subsample2(const void* x, void* out, int B, int H, int W, int C, hipStream_t stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return DDL_EINVAL;
+    if ((C & 7) || !ddl_aligned16(x) || !ddl_aligned16(out)) return DDL_EALIGN;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, cvec = C / 8;
+    const long long total = (long long)B * Ho * Wo * cvec;
+    if ((total + 255) / 256 > 0x7fffffffLL) return DDL_EINVAL;
+    DDL_KLAUNCH(subsample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const u32x4*)x, (u32x4*)out, H, W,
+                Ho, Wo, cvec, total);
+    return ddl_launch_status();
+}
 
 extern "C" int ddl_pool_gather(const void* pool, const void* pool_labels, void* out, void* out_labels, void* state,
                                int pool_size, int batch, long long row_bytes, unsigned long long seed, hipStream_t stream) {

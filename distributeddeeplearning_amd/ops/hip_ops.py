@@ -1222,7 +1222,7 @@ class ResidualBlockFn(Function):
         # pre-masked gradient and the BatchNorm partials, i.e. it will take the linear path
         lin_chain = bool(cfg[9]) and _FUSE_BN_REDUCE["on"]
         if training and has_ds and lin_chain and _FUSE_DS_REDUCE["on"] and _lin_ds_static_ok(groups[units][0], ds_stride, x):
-            ctx.lin_xs = x if ds_stride == 1 else x[:, :, ::2, ::2].contiguous(memory_format=_CL)
+            ctx.lin_xs = x if ds_stride == 1 else K.subsample2(x)
             ctx.lin_pre_ds = _bn3_linear_gram_forward(ctx.lin_xs, groups[units][0])
         for i in range(units):
             w, g, b, rm, rv = groups[i]
@@ -1360,7 +1360,7 @@ class ResidualBlockFn(Function):
                         # x_s the input at the pixels the strided 1x1 conv visits): dyd never exists
                         xs = getattr(ctx, "lin_xs", None)
                         if xs is None:
-                            xs = x if ds_stride == 1 else x[:, :, ::2, ::2].contiguous(memory_format=_CL)
+                            xs = x if ds_stride == 1 else K.subsample2(x)
                         coef_d, dgd, dbd = _unit_coef(g_short, yd, gd, bd, cd, fused_ds)
                         pre = _side_prewait(g_short.device)
                         addend, _ = _bn3_linear_dgrad(g_short, xs, wd, coef_d, None, None)

@@ -532,6 +532,18 @@ def stem_pack(x, out):
                               _i64(sw), _i64(sc), stream()), "stem_pack")
 
 
+def subsample2(x):
+    """Every second row and column of a dense NHWC (channels_last) bf16 tensor - what a stride-2 1x1
+    projection reads - as a dense NHWC tensor (replaces ``x[:, :, ::2, ::2].contiguous()``)."""
+    B, C, H, W = x.shape
+    if x.dtype != torch.bfloat16 or x.stride() != (H * W * C, 1, W * C, C):
+        raise ValueError("subsample2: dense channels_last bf16 input expected, got %s %s" % (x.dtype, x.stride()))
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    out = torch.empty_strided((B, C, Ho, Wo), (Ho * Wo * C, 1, Wo * C, C), dtype=x.dtype, device=x.device)
+    check(lib().ddl_subsample2(ptr(x), ptr(out), _i32(B), _i32(H), _i32(W), _i32(C), stream()), "subsample2")
+    return out
+
+
 # ---- direct xGMI all-reduce and multi-tensor pack (csrc/kernels/xgmi_allreduce.hip) ----------
 def xgmi_allreduce(buf_ptrs, flag_ptrs, out_ptrs, count, rank, nranks, is_bf16, one_shot, epoch,
                    scale, timeout_word, blocks=16, spin_limit=2_000_000, simulate=False):

@@ -106,10 +106,12 @@ class _ArenaOptimizer(Optimizer):
         moved.  HIP kernels only; the CPU reference path keeps reading ``lr`` directly."""
         if self.lr_scale is None:
             lr = float(self.param_groups[0]["lr"])
-            # a warm-up that starts at lr = 0 must not freeze a zero: the by-value factor is 1.0
-            # then and the device scalar carries the absolute learning rate
-            self._frozen_lr = lr if lr != 0.0 else 1.0
-            self._scale_written = lr / self._frozen_lr
+            # the by-value factor is exactly 1.0 and the device scalar carries the absolute learning
+            # rate: 1.0f * fp32(lr) is the very float the by-value path passes, so a frozen step is
+            # bit-identical to an unfrozen one (a ratio lr / lr0 is not: fp32(lr0) * fp32(lr / lr0)
+            # rounds differently, tests/test_gpu_tape.py)
+            self._frozen_lr = 1.0
+            self._scale_written = lr
             self.lr_scale = torch.full((1,), self._scale_written, dtype=torch.float32,
                                        device=self.arena.device)
         return self.lr_scale

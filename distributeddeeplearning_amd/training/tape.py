@@ -34,6 +34,7 @@ What makes a step recordable, and what guards it:
 """
 from __future__ import annotations
 
+import traceback
 import warnings
 
 import torch
@@ -63,6 +64,7 @@ class KernelOpWatch(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.seen = {}
+        self.where = {}     # operator -> innermost frames of its first occurrence (who to blame)
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
@@ -73,6 +75,10 @@ class KernelOpWatch(TorchDispatchMode):
             touched = any(isinstance(a, torch.Tensor) and a.is_cuda for a in _flat(args, kwargs, out))
             if touched:
                 self.seen[name] = self.seen.get(name, 0) + 1
+                if name not in self.where:
+                    frames = traceback.extract_stack()[:-1]
+                    self.where[name] = ["%s:%d %s" % (f.filename.rsplit("/", 1)[-1], f.lineno, f.name)
+                                        for f in frames[-4:]] or ["<autograd engine, no Python frame>"]
         return out
 
 
@@ -105,6 +111,7 @@ class TapedTrainStep:
         self.launches = 0
         self.failed = None
         self.foreign_ops = None
+        self.foreign_where = None
         self._pool = None
         self._ones = None
         self._static_in = None
@@ -185,9 +192,11 @@ class TapedTrainStep:
             torch._C._cuda_endAllocateToPool(dev, pool.id)
             torch._C._cuda_releasePool(dev, pool.id)
         self.foreign_ops = dict(watch.seen)
+        self.foreign_where = dict(watch.where)
         if watch.seen and self.strict:
             _tape.free(rec.tape)
-            self.failed = _tape.TapeError("framework operators inside the step: %s" % sorted(watch.seen.items()))
+            self.failed = _tape.TapeError("framework operators inside the step: %s; first seen at %s"
+                                          % (sorted(watch.seen.items()), watch.where))
             self._static_in = None
             warnings.warn("the training step is not recordable - it ran framework operators that a replay would "
                           "skip: %s; continuing eagerly" % sorted(watch.seen.items()))

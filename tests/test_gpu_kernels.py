@@ -1061,3 +1061,15 @@ def test_training_is_bit_reproducible_and_independent_of_the_side_stream():
     lc, wc = run(False)
     assert la == lb == lc, (la, lb, lc)
     assert torch.equal(wa, wb) and torch.equal(wa, wc)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 8, 8), (2, 256, 7, 9), (4, 8, 1, 5)])
+def test_subsample2_is_the_strided_slice(shape):
+    """ddl_subsample2 (input of the stride-2 projections, csrc/kernels/step_aux.hip) against slicing."""
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    x = torch.randn(shape, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out = K.subsample2(x)
+    ref = x[:, :, ::2, ::2]
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out, ref)
