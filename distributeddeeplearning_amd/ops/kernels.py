@@ -234,6 +234,10 @@ def _i32(v):
     return ctypes.c_int(int(v))
 
 
+# diagnostic: a list that receives one tuple per conv launch (scripts/conv_roofline.py); None = off
+LAUNCH_LOG = None
+
+
 def nhwc_dims(x):
     """(B, C, H, W, stride_b, stride_h, stride_w) of a logically-NCHW tensor stored NHWC."""
     assert x.dim() == 4
@@ -270,6 +274,11 @@ def conv_igemm(x_ptr_tensor, geom, w, y, n_out, R, S, ostride, pad, pad_w, idil,
     ``ep_maskbits`` (uint8, one bit per output element, from :func:`bn_apply_fwd`) replaces
     ``ep_mask``."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG.append(("conv_igemm", B, Hin, Win, C, Hout, Wout, n_out, R, S, ostride, idil, y.numel() // n_out,
+                           int(addend is not None), int(stats is not None), int(ep_y is not None),
+                           int(ep_mask is not None or ep_maskbits is not None), int(ep_y2 is not None),
+                           int(bool(wt_rows)), c2))
     for t in (ep_y, ep_mask, ep_y2):
         if t is not None and t.numel() != y.numel():
             raise KernelError("conv_igemm: epilogue tensor does not match the output shape")
@@ -314,6 +323,8 @@ def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hou
                stream=None):
     """``partial``: tensor or raw address; ``stream``: raw HIP stream (default: current)."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG.append(("conv_wgrad", B, Hin, Win, C, Hout, Wout, K, R, S, stride, 1, dy.numel() // K, splits))
     f = _fn("ddl_conv_wgrad", "ppp qq iiii qqq iiiiiiiii p")
     check(f(dy.data_ptr(), x_ptr_tensor.data_ptr(), _p(partial), dy.numel(), xn, B, Hin, Win,
             C, sb, sh, sw, Hout, Wout, K, R, S, stride, pad, pad_w, splits,
