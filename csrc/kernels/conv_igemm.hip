@@ -816,46 +816,3 @@ extern "C" int ddl_conv_igemm_ex4(const void* x, const void* w, void* y, const v
     }
     return deep ? launch_cfg<128, 128, 64>(p, stream) : launch_cfg<128, 128, 32>(p, stream);
 }
-
-extern "C" int ddl_conv_igemm_ex3(const void* x, const void* w, void* y, const void* addend, void* stats,
-                                  long long x_numel, long long w_numel,
-                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
-                                  int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
-                                  int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
-                                  const void* ep_y2, void* stats2, const void* ep_maskbits, int wt, int wt_rows,
-                                  hipStream_t stream) {
-    return ddl_conv_igemm_ex4(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
-                              N, R, S, ostride, pad, pad_w, idil, addend_sub2, ep_y, ep_fcoef, ep_mask, ep_y2, stats2,
-                              ep_maskbits, wt, wt_rows, nullptr, nullptr, 0, 0, 0, nullptr, stream);
-}
-
-extern "C" int ddl_conv_igemm_ex2(const void* x, const void* w, void* y, const void* addend, void* stats,
-                                  long long x_numel, long long w_numel,
-                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
-                                  int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
-                                  int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
-                                  const void* ep_y2, void* stats2, const void* ep_maskbits, hipStream_t stream) {
-    return ddl_conv_igemm_ex3(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
-                              N, R, S, ostride, pad, pad_w, idil, addend_sub2, ep_y, ep_fcoef, ep_mask, ep_y2, stats2,
-                              ep_maskbits, 0, 0, stream);
-}
-
-extern "C" int ddl_conv_igemm_ex(const void* x, const void* w, void* y, const void* addend, void* stats,
-                                 long long x_numel, long long w_numel,
-                                 int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
-                                 int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
-                                 int addend_sub2, const void* ep_y, const void* ep_fcoef, const void* ep_mask,
-                                 hipStream_t stream) {
-    return ddl_conv_igemm_ex2(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
-                              N, R, S, ostride, pad, pad_w, idil, addend_sub2, ep_y, ep_fcoef, ep_mask, nullptr, nullptr,
-                              nullptr, stream);
-}
-
-extern "C" int ddl_conv_igemm(const void* x, const void* w, void* y, const void* addend, void* stats,
-                              long long x_numel, long long w_numel,
-                              int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
-                              int Hout, int Wout, int N, int R, int S, int ostride, int pad, int pad_w, int idil,
-                              int addend_sub2, hipStream_t stream) {
-    return ddl_conv_igemm_ex(x, w, y, addend, stats, x_numel, w_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout,
-                             N, R, S, ostride, pad, pad_w, idil, addend_sub2, nullptr, nullptr, nullptr, stream);
-}
