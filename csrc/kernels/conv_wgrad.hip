@@ -270,6 +270,223 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
         }
 }
 
+// ---- 256 x 256 tile, 8 waves, LDS-DMA ring with tiles in flight across the barrier ----------------
+// The matrix-bound weight gradients (stages 3-4: 256..2048 channels on both sides; reduction 12 544 or
+// 50 176 rows) ran at 600-730 TFLOP/s in the 128 x 128 / 4-wave kernel above: at the ceiling of a loop
+// that drains its LDS-DMA (`vmcnt(0)`) and meets at a barrier every 32 reduction rows with one tile
+// in flight.  This kernel is built the other way round (cdna_hip_programming.md section 5, "Pipelining
+// across barriers"):
+//   * one 256 x 256 fp32 tile per workgroup, 8 waves as 2 (n) x 4 (r,s,c); a wave owns 128 x 64 =
+//     8 x 4 MFMA fragments (128 accumulator registers): 32 MFMAs per 24 transposing LDS reads and
+//     per barrier instead of 16 per 16;
+//   * NST LDS stages of 32 reduction rows (32 KB each: dy [32][256] + x [32][256]), filled by LDS-DMA
+//     only; the DMA of tile t+NST-1 is issued before tile t is consumed and is waited for with a COUNTED
+//     `s_waitcnt vmcnt(4 * (NST-2))` - never 0 inside the loop - followed by a raw `s_barrier`;
+//   * a stage is overwritten one barrier after its last read retired (`lgkmcnt(0)` before that barrier).
+// Rows are 512 bytes: window w (32 bytes) of row r sits at window w ^ (r & 7) as in the kernel above,
+// applied on the SOURCE address of the DMA (the LDS image of one wave-instruction is linear) and on
+// the read address.
+// One 16-byte-per-lane LDS-DMA, issued so that hipcc does not see it: the compiler orders every LDS read
+// after ALL LDS-DMA it knows to be in flight (`s_waitcnt vmcnt(0)` in front of the first ds_read of each
+// tile - seen in the .s of the builtin form), which empties the ring.  Hidden in inline asm, the DMA is
+// ordered by this kernel's own counted waits.  `lds_addr` (byte address of the wave's 1 KiB piece) and
+// `soff` are wave-uniform; one wait state separates the write of M0 from its use.
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+
+template <bool SIMPLE, int NST>
+__global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p) {
+    constexpr int BK = 32, ROWB = 512, HALF = BK * ROWB, STAGE = 2 * HALF, CPR = 32, LOADS = 2;
+    constexpr int FM = 8, FN = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+
+    const int ntile = p.tiles_k * p.tiles_rsc;
+    const int nwg = ntile * p.splits;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int split = bid / ntile;
+    const int t = bid - split * ntile;
+    const int tile_k = t % p.tiles_k, tile_j = t / p.tiles_k;
+    const int n0 = tile_k * 256, j0 = tile_j * 256;
+    const int RSC = p.R * p.S * p.C;
+
+    const int m_begin = split * p.m_per_split;
+    int m_end = m_begin + p.m_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int KT = (m_end - m_begin + BK - 1) / BK;
+
+    const int hw = p.Hout * p.Wout;
+    const int b_first = m_begin / hw;
+    const long long dy_first = (long long)m_begin * p.K;
+    const long long x_first = SIMPLE ? (long long)m_begin * p.xs_w : (long long)b_first * p.xs_b;
+    long long dy_left = p.dy_bytes - dy_first * 2, x_left = p.x_bytes - x_first * 2;
+    dy_left = dy_left < 0 ? 0 : (dy_left > 0x7fffffffLL ? 0x7fffffffLL : dy_left);
+    x_left = x_left < 0 ? 0 : (x_left > 0x7fffffffLL ? 0x7fffffffLL : x_left);
+    const u32x4 dyr = raw_rsrc(p.dy + dy_first, (unsigned)dy_left), xr = raw_rsrc(p.x + x_first, (unsigned)x_left);
+
+    constexpr unsigned INVALID = 0x80000000u;
+    unsigned a_voff[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int idx = tid + i * 512;
+        const int row = idx / CPR;
+        int ch = idx - row * CPR;
+        ch = (((ch >> 1) ^ (row & 7)) << 1) | (ch & 1);          // physical position -> logical chunk
+        const int n = n0 + ch * 8;
+        a_voff[i] = (n < p.K) ? ((unsigned)row * (unsigned)p.K + (unsigned)n) * 2u : INVALID;
+    }
+    int b_wo[LOADS], b_ho[LOADS], b_dh[LOADS], b_dw[LOADS];
+    unsigned b_base[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int idx = tid + i * 512;
+        const int row = idx / CPR;
+        int ch = idx - row * CPR;
+        ch = (((ch >> 1) ^ (row & 7)) << 1) | (ch & 1);
+        const int j = j0 + ch * 8;
+        const int tap = j0 / p.C, c = j - tap * p.C;            // C is a multiple of 256: one tap per tile
+        const int fr = tap / p.S, fs = tap - fr * p.S;
+        const bool live = j < RSC;
+        b_dh[i] = fr - p.pad;
+        b_dw[i] = fs - p.pad_w;
+        const int m = m_begin + row;
+        if (SIMPLE) {
+            b_base[i] = live ? ((unsigned)row * (unsigned)p.xs_w + (unsigned)c) * 2u : INVALID;
+            b_wo[i] = 0; b_ho[i] = 0;
+        } else {
+            const int b = m / hw, rem = m - b * hw;
+            const int ho = rem / p.Wout, wo = rem - ho * p.Wout;
+            b_wo[i] = wo;
+            b_ho[i] = live ? ho : -(1 << 24);
+            b_base[i] = (unsigned)(((b - b_first) * (int)p.xs_b + (ho * p.stride + fr - p.pad) * (int)p.xs_h + c) * 2);
+        }
+    }
+    const int step_w = BK % p.Wout, step_h = BK / p.Wout;
+    const int xs_w2 = (int)p.xs_w * 2;
+    const int row_bytes = p.stride * (int)p.xs_h * 2;
+    const int img_bytes = (int)p.xs_b * 2 - p.Hout * row_bytes;
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_ptr)smem;
+    // every call issues exactly 4 LDS-DMA instructions per thread (rows past the end read as zeros):
+    // the counted waits below rely on it
+    auto fetch = [&](int kt, int stage) {
+        const int rows_left = m_end - (m_begin + kt * BK);
+        const int a_soff = kt * (BK * 2) * p.K;
+        const unsigned Ad = lds0 + (unsigned)(stage * STAGE + wid * 1024), Bd = Ad + HALF;
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int row = (tid + i * 512) / CPR;
+            const int vo = (int)(row < rows_left ? a_voff[i] : INVALID);
+            lds_dma16(dyr, Ad + i * 8192, (unsigned)vo, (unsigned)a_soff);
+        }
+        if (SIMPLE) {
+            const int b_soff = kt * BK * xs_w2;
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int row = (tid + i * 512) / CPR;
+                const int vo = (int)(row < rows_left ? b_base[i] : INVALID);
+                lds_dma16(xr, Bd + i * 8192, (unsigned)vo, (unsigned)b_soff);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int hi = b_ho[i] * p.stride + b_dh[i], wi = b_wo[i] * p.stride + b_dw[i];
+                const int row = (tid + i * 512) / CPR;
+                const bool ok = (row < rows_left) & (hi >= 0) & (hi < p.Hin) & (wi >= 0) & (wi < p.Win);
+                const unsigned vo = ok ? b_base[i] + (unsigned)(wi * xs_w2) : INVALID;
+                lds_dma16(xr, Bd + i * 8192, vo, 0u);
+                int wo = b_wo[i] + step_w, ho = b_ho[i] + step_h;
+                unsigned base = b_base[i] + (unsigned)(step_h * row_bytes);
+                if (wo >= p.Wout) { wo -= p.Wout; ++ho; base += (unsigned)row_bytes; }
+                while (ho >= p.Hout) { ho -= p.Hout; base += (unsigned)img_bytes; }
+                b_wo[i] = wo; b_ho[i] = ho; b_base[i] = base;
+            }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int tr_row = 4 * g + q, swz = tr_row & 7;
+    // byte offsets of this lane's fragment reads inside a stage (row tr_row; the second half of a fragment is 16 rows down)
+    int a_off[FM], b_off[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a_off[i] = tr_row * ROWB + (((wm * 8 + i) ^ swz) * 32) + 8 * pq;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b_off[j] = HALF + tr_row * ROWB + (((wn * 4 + j) ^ swz) * 32) + 8 * pq;
+
+    // prologue: NST-1 tiles in flight, the first one landed
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0) fetch(s0, s0);
+    if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (NST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0, nxt = NST - 1;
+    for (int kt = 0; kt < KT; ++kt) {
+        fetch(kt + NST - 1, nxt);              // into the stage whose last reads retired before the previous barrier
+        unsigned char* St = smem + cur * STAGE;
+        bf16x8 af[FM], bfr[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + b_off[j]));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + b_off[j] + 16 * ROWB));
+            bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + a_off[i]));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + a_off[i] + 16 * ROWB));
+            af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        // tile kt+1 has landed (this wave's part; the barrier makes it everyone's); every LDS read of this
+        // tile has retired, so the next iteration may overwrite the stage
+        if (NST == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (NST == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        nxt = cur;
+        cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-filled tiles past the end
+
+    float* out = p.partial + (long long)split * p.K * RSC;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int jc = j0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wm * 128 + i * 16 + fq * 4 + e;
+                if (n < p.K && jc < RSC) out[(long long)n * RSC + jc] = acc[i][j][e];
+            }
+        }
+}
+
 // out[i] = sum_s partial[s][i] (fixed order => deterministic), bf16 or fp32 output.
 // Block = (256 / SL) float4 columns x SL split lanes, so that tall-and-narrow reductions (a 64x64
 // 1x1 conv weight summed over 512 slabs) still spread over many CUs with short dependent chains.
@@ -437,7 +654,29 @@ static void wgrad_tile(int K, int C, int R, int S, int& bm, int& bn) {
     }
 }
 
+// The 256 x 256 / 8-wave kernel serves problems whose output is made of whole 256 x 256 tiles with one
+// filter tap per tile.  DDL_WGRAD_BIG=0|1 (default below), DDL_WGRAD_BIG_TARGET = workgroups to aim for
+// (one per CU fits: 96-128 KB of LDS each), DDL_WGRAD_BIG_NST = LDS stages (3 or 4).
+static bool wgrad_big(long long M, int K, int C, int R, int S) {
+    static const int on = getenv("DDL_WGRAD_BIG") ? atoi(getenv("DDL_WGRAD_BIG")) : 1;  // tuning knob
+    return on && K % 256 == 0 && C % 256 == 0 && M >= 4096;
+}
+static int wgrad_big_splits(long long M, int K, int C, int R, int S) {
+    // In the training step fewer, longer workgroups win (each costs 256 KB of partial-sum traffic and one CU's
+    // LDS): 64 / 96 / 128 / 160 / 192 / 256 workgroups -> 18.13 / 17.85 / 17.80 / 17.70 / 17.73 / 18.01 ms per step
+    // against 18.18-18.24 ms with the 128 x 128 kernel (profiles/r3_notes.md)
+    static const int target = getenv("DDL_WGRAD_BIG_TARGET") ? atoi(getenv("DDL_WGRAD_BIG_TARGET")) : 160;  // tuning knob
+    const long long tiles = (long long)(K / 256) * ((long long)R * S * C / 256);
+    long long want = (target + tiles / 2) / tiles;
+    const long long max_by_m = M / 512;                    // at least 16 tiles of 32 rows per split
+    if (want > max_by_m) want = max_by_m;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    return (int)want;
+}
+
 extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S) {
+    if (wgrad_big(M, K, C, R, S)) return wgrad_big_splits(M, K, C, R, S);
     int bm, bn;
     wgrad_tile(K, C, R, S, bm, bn);
     long long tiles = (long long)((K + bm - 1) / bm) * ((R * S * C + bn - 1) / bn);
@@ -492,6 +731,20 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
     if ((mps / ((long long)Hout * Wout) + 3) * xs_b * 2 >= 0x7fffffffLL || (mps + 64) * xs_w * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0 && pad_w == 0 && Hin == Hout && Win == Wout &&
                 xs_h == (long long)Win * xs_w && xs_b == (long long)Hin * xs_h) ? 1 : 0;
+    if (wgrad_big(M, K, C, R, S)) {
+        static const int nst = getenv("DDL_WGRAD_BIG_NST") ? atoi(getenv("DDL_WGRAD_BIG_NST")) : 3;  // tuning knob
+        p.tiles_k = K / 256;
+        p.tiles_rsc = R * S * C / 256;
+        dim3 grid(p.tiles_k * p.tiles_rsc * p.splits), block(512);
+        if (nst == 4) {
+            if (p.simple) DDL_KLAUNCH((conv_wgrad256_kernel<true, 4>), grid, block, 0, stream, p);
+            else DDL_KLAUNCH((conv_wgrad256_kernel<false, 4>), grid, block, 0, stream, p);
+        } else {
+            if (p.simple) DDL_KLAUNCH((conv_wgrad256_kernel<true, 3>), grid, block, 0, stream, p);
+            else DDL_KLAUNCH((conv_wgrad256_kernel<false, 3>), grid, block, 0, stream, p);
+        }
+        return ddl_launch_status();
+    }
     int bm, bn;
     wgrad_tile(K, C, R, S, bm, bn);
     if (bm == 64) {
