@@ -48,6 +48,20 @@ __device__ __forceinline__ int lds_swz(int row) {
     return ROW_BYTES == 256 ? (row & 7) : ((row >> 1) & 3);
 }
 
+// One 16-byte-per-lane LDS-DMA, issued so that hipcc does not see it: the compiler orders every LDS read
+// after ALL LDS-DMA it knows to be in flight (`s_waitcnt vmcnt(0)` in front of the first ds_read of each
+// tile - seen in the .s of the builtin form), which empties the ring.  Hidden in inline asm, the DMA is
+// ordered by this kernel's own counted waits.  `lds_addr` (byte address of the wave's 1 KiB piece) and
+// `soff` are wave-uniform; one wait state separates the write of M0 from its use.
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+
 template <int BMw, int BNw, bool SIMPLE, bool UNITAP, bool GLDS, int BK = 32>
 __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p) {
     static_assert(!GLDS || ((BMw == 64 || BMw == 128) && (BNw == 64 || BNw == 128)), "LDS-DMA image: 128- or 256-byte rows");
@@ -97,6 +111,12 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     x_left = x_left < 0 ? 0 : (x_left > 0x7fffffffLL ? 0x7fffffffLL : x_left);
     const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + dy_first), 0, (int)dy_left, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + x_first), 0, (int)x_left, 0x00020000);
+    // GLDS: the DMA is issued from inline asm (lds_dma16) - in its builtin form hipcc drains it (vmcnt(0)) in
+    // front of the first transposing LDS read of every tile, i.e. the next tile's DMA never overlapped this
+    // tile's MFMAs inside a workgroup
+    const u32x4 dyq = raw_rsrc(p.dy + dy_first, (unsigned)dy_left), xq = raw_rsrc(p.x + x_first, (unsigned)x_left);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
 
     // Per-thread load slots are fixed over the whole reduction: (row, chunk) never change and the
     // pixel index only advances by BK per tile.  dy offsets therefore ride in the buffer
@@ -150,13 +170,12 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     auto fetch = [&](int kt, int stage) {
         const int rows_left = m_end - (m_begin + kt * BK);
         const int a_soff = kt * (BK * 2) * p.K;
-        unsigned char* Ad = smem + stage * STAGE + wid * 1024;
-        unsigned char* Bd = Ad + A_BYTES;
+        const unsigned Ad = lds0 + (unsigned)(stage * STAGE + wid_u * 1024), Bd = Ad + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int row = (tid + i * 256) / A_CPR;
             const int vo = (int)(row < rows_left ? a_voff[i] : INVALID);
-            if (GLDS) __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, (lds_void_ptr)(Ad + i * 4096), 16, vo, a_soff, 0, 0);
+            if (GLDS) lds_dma16(dyq, Ad + i * 4096, (unsigned)vo, (unsigned)a_soff);
             else a_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyr, vo, a_soff, 0);
         }
         if (SIMPLE) {
@@ -165,7 +184,7 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
             for (int i = 0; i < B_LOADS; ++i) {
                 const int row = (tid + i * 256) / B_CPR;
                 const int vo = (int)(row < rows_left ? b_base[i] : INVALID);
-                if (GLDS) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(Bd + i * 4096), 16, vo, b_soff, 0, 0);
+                if (GLDS) lds_dma16(xq, Bd + i * 4096, (unsigned)vo, (unsigned)b_soff);
                 else b_reg[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, b_soff, 0);
             }
         } else {
@@ -175,7 +194,7 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
                 const int row = (tid + i * 256) / B_CPR;
                 bool ok = (row < rows_left) & (hi >= 0) & (hi < p.Hin) & (wi >= 0) & (wi < p.Win);
                 const unsigned vo = ok ? b_base[i] + (unsigned)(wi * xs_w2) : INVALID;
-                if (GLDS) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(Bd + i * 4096), 16, (int)vo, 0, 0, 0);
+                if (GLDS) lds_dma16(xq, Bd + i * 4096, vo, 0u);
                 else b_reg[i] = wg_load16(xr, vo);
                 // advance this slot by BK pixels
                 int wo = b_wo[i] + step_w, ho = b_ho[i] + step_h;
@@ -286,20 +305,6 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
 // Rows are 512 bytes: window w (32 bytes) of row r sits at window w ^ (r & 7) as in the kernel above,
 // applied on the SOURCE address of the DMA (the LDS image of one wave-instruction is linear) and on
 // the read address.
-// One 16-byte-per-lane LDS-DMA, issued so that hipcc does not see it: the compiler orders every LDS read
-// after ALL LDS-DMA it knows to be in flight (`s_waitcnt vmcnt(0)` in front of the first ds_read of each
-// tile - seen in the .s of the builtin form), which empties the ring.  Hidden in inline asm, the DMA is
-// ordered by this kernel's own counted waits.  `lds_addr` (byte address of the wave's 1 KiB piece) and
-// `soff` are wave-uniform; one wait state separates the write of M0 from its use.
-__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-}
-
 template <bool SIMPLE, int NST, bool PIPE>
 __global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p) {
     constexpr int BK = 32, ROWB = 512, HALF = BK * ROWB, STAGE = 2 * HALF, CPR = 32, LOADS = 2;
