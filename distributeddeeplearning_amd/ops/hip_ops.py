@@ -372,7 +372,7 @@ def _conv_wgrad(dy, x, w, stride, padding, prewaited=False):
     Kc, _, R, S = w.shape
     Ho, Wo = dy.shape[2], dy.shape[3]
     if _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]:
-        side = _side_stream(dy.device) if _SIDE["on"] else None
+        side = _side_stream(dy.device) if (_SIDE["on"] and Ho * Wo < _SIDE_MAX_HW) else None
         if side is None:
             _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
                         accumulate=True)
@@ -417,6 +417,9 @@ import os as _os
 _SIDE = {"on": _os.environ.get("DDL_WGRAD_SIDE_STREAM", "1") != "0",   # 0: weight gradients on the main stream
          "stream": None, "pending": False, "event": None, "ws": None, "keep": [], "join_queued": False}
 _SIDE_LEAN = _os.environ.get("DDL_SIDE_LEAN", "1") != "0"
+# weight gradients of layers with at least this many output pixels per image run on the MAIN stream
+# (probe: do the bandwidth-bound early layers gain anything from a second stream?)
+_SIDE_MAX_HW = int(_os.environ.get("DDL_SIDE_MAX_HW", str(1 << 30)))
 
 
 def _side_workspace(nbytes):
@@ -842,7 +845,7 @@ def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None):
     C, C2 = w.shape[0], w.shape[1]
     direct = _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]
     out = w.grad if direct else torch.zeros_like(w)
-    side = _side_stream(g.device) if (_SIDE["on"] and direct) else None
+    side = _side_stream(g.device) if (_SIDE["on"] and direct and g.shape[2] * g.shape[3] < _SIDE_MAX_HW) else None
     B, _, H, W = g.shape
     M = B * H * W
     splits = K.conv_wgrad_splits(M, C, C2, 1, 1)      # raw product g^T z2

@@ -78,7 +78,7 @@ def join(trace_csv, log_json):
     log = json.load(open(log_json))
     out = []
     for kind in ("conv_igemm", "conv_wgrad"):
-        ks = [r for r in step if kind + "_kernel" in r["Kernel_Name"]]
+        ks = [r for r in step if kind + "_kernel" in r["Kernel_Name"] or (kind == "conv_wgrad" and "conv_wgrad256_kernel" in r["Kernel_Name"])]
         ls = [r for r in log if r[0] == kind]
         if len(ks) != len(ls):
             print("# %s: %d kernels in the trace, %d launches logged - not joined" % (kind, len(ks), len(ls)))
