@@ -28,39 +28,35 @@ __device__ __forceinline__ uint32_t px_first(uint64_t counter, uint64_t seed) {
 
 // ---- synthetic loader: index draw + gather of images and labels in ONE launch -------------------
 // state[0] = batches drawn so far (device-side, so that a recorded launch replays with fresh
-// indices), state[1] = arrival ticket.  Sample b of the batch takes pool row
-// philox(seed, state[0] * batch + b) mod pool_size - the reference's random translation index
-// (HorovodPytorch/src/imagenet_pytorch_horovod.py:162-166,177-188), drawn where it is used.
-// Grid (chunks, batch): every block copies one 16-byte-vector chunk of one image.  The block that
-// arrives last (every block has read state[0] by then) advances the counter.
+// indices).  Sample b of the batch takes pool row philox(seed, state[0] * batch + b) mod pool_size -
+// the reference's random translation index (HorovodPytorch/src/imagenet_pytorch_horovod.py:162-166,
+// 177-188), drawn where it is used.  Grid (chunks, batch): every block copies one 16-byte-vector chunk
+// of one image, eight vectors per thread in flight.  The counter is advanced by a one-thread kernel
+// queued behind this one: an arrival ticket (one same-address device-scope atomic per block, 2560 of
+// them) cost 150 of this kernel's 176 us (profiles/r3_notes.md).
 __global__ void __launch_bounds__(256) pool_gather_kernel(const u32x4* __restrict__ pool, const long long* __restrict__ pool_labels,
                                                           u32x4* __restrict__ out, long long* __restrict__ out_labels,
-                                                          unsigned long long* __restrict__ state, int pool_size, int batch,
+                                                          const unsigned long long* __restrict__ state, int pool_size, int batch,
                                                           long long row_vec, uint64_t seed) {
-    __shared__ unsigned row_s;
     const int b = blockIdx.y;
-    if (threadIdx.x == 0) {
-        const unsigned long long step = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        row_s = px_first(step * (unsigned long long)batch + (unsigned long long)b, seed) % (unsigned)pool_size;
-    }
-    __syncthreads();
-    const unsigned row = row_s;
+    const unsigned long long step = state[0];
+    const unsigned row = px_first(step * (unsigned long long)batch + (unsigned long long)b, seed) % (unsigned)pool_size;
     const long long per = (row_vec + gridDim.x - 1) / gridDim.x;
     const long long lo = per * blockIdx.x, hi = lo + per < row_vec ? lo + per : row_vec;
     const u32x4* src = pool + (long long)row * row_vec;
     u32x4* dst = out + (long long)b * row_vec;
-    for (long long i = lo + threadIdx.x; i < hi; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
-    if (blockIdx.x == 0 && threadIdx.x == 0) out_labels[b] = pool_labels[row];
-    __syncthreads();   // thread 0 read state[0] before this block's arrival is counted
-    if (threadIdx.x == 0) {
-        const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
-        const unsigned long long t = __hip_atomic_fetch_add(state + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == total - 1) {
-            __hip_atomic_store(state + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(state, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    long long i = lo + threadIdx.x;
+    for (; i + 7 * 256 < hi; i += 8 * 256) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[i + u * 256] = v[u];
     }
+    for (; i < hi; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_labels[b] = pool_labels[row];
 }
+__global__ void pool_gather_advance_kernel(unsigned long long* __restrict__ state) { state[0] += 1; }
 
 // ---- stem filter: [K][7][7][C<=4] (KRSC bf16) -> [K][7][8][4] zero-padded "row of taps" image ----
 __global__ void __launch_bounds__(256) stem_weight_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int K, int C) {
@@ -126,8 +122,9 @@ extern "C" int ddl_pool_gather(const void* pool, const void* pool_labels, void* 
     if (chunks < 1) chunks = 1;
     if (chunks > 64) chunks = 64;
     DDL_KLAUNCH(pool_gather_kernel, dim3(chunks, batch), dim3(256), 0, stream, (const u32x4*)pool,
-                       (const long long*)pool_labels, (u32x4*)out, (long long*)out_labels, (unsigned long long*)state,
+                       (const long long*)pool_labels, (u32x4*)out, (long long*)out_labels, (const unsigned long long*)state,
                        pool_size, batch, row_vec, (uint64_t)seed);
+    DDL_KLAUNCH(pool_gather_advance_kernel, dim3(1), dim3(1), 0, stream, (unsigned long long*)state);
     return ddl_launch_status();
 }
 
