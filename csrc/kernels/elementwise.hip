@@ -237,6 +237,23 @@ __global__ void __launch_bounds__(256) fused_lars_kernel(float* __restrict__ w, 
     }
 }
 
+// trust ratio per segment from the squared norms: tc*|w| / (|g| + wd*|w| + eps), 1 where either norm is 0
+// (in-tree so that a LARS step contains no framework operator and can be replayed from the launch tape)
+__global__ void __launch_bounds__(256) lars_trust_ratio_kernel(const float* __restrict__ sq /*[2][nseg]*/, int nseg, float tc,
+                                                              float wd, float eps, float* __restrict__ ratio) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nseg) return;
+    const float wn = sqrtf(sq[k]), gn = sqrtf(sq[nseg + k]);
+    ratio[k] = (wn > 0.f && gn > 0.f) ? tc * wn / (gn + wd * wn + eps) : 1.f;
+}
+
+extern "C" int ddl_lars_trust_ratios(const void* sq, int nseg, float tc, float wd, float eps, void* ratio, hipStream_t stream) {
+    if (!sq || !ratio || nseg <= 0) return DDL_EINVAL;
+    DDL_KLAUNCH(lars_trust_ratio_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, (const float*)sq, nseg, tc, wd, eps,
+                (float*)ratio);
+    return ddl_launch_status();
+}
+
 extern "C" int ddl_segmented_sqnorms(const void* w, const void* g, int grad_is_bf16, const void* seg_start,
                                      const void* seg_end, int nseg, long long n, void* out, hipStream_t stream) {
     if (!w || !g || !seg_start || !seg_end || !out || nseg <= 0 || n <= 0) return DDL_EINVAL;

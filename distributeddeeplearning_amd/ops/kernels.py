@@ -202,6 +202,19 @@ def segmented_norms(w, g, seg_offsets, seg_ends):
     return out[0], out[1]
 
 
+def lars_trust_ratios(w, g, seg_offsets, seg_ends, trust_coefficient, wd, eps):
+    """K15 passes 1 + 1b without a framework operator: squared norms per segment, then
+    ``tc*|w| / (|g| + wd*|w| + eps)`` (1 where a norm is zero) - an fp32 [nseg] tensor."""
+    nseg = seg_ends.numel()
+    buf = torch.empty((3, nseg), dtype=torch.float32, device=w.device)
+    check(lib().ddl_segmented_sqnorms(ptr(w), ptr(g), ctypes.c_int(int(g.dtype == torch.bfloat16)),
+                                      ptr(seg_offsets), ptr(seg_ends), ctypes.c_int(nseg),
+                                      _i64(w.numel()), ptr(buf), stream()), "segmented_sqnorms")
+    check(lib().ddl_lars_trust_ratios(ptr(buf), ctypes.c_int(nseg), _f32(trust_coefficient), _f32(wd), _f32(eps),
+                                      ctypes.c_void_p(buf.data_ptr() + 8 * nseg), stream()), "lars_trust_ratios")
+    return buf[2]
+
+
 def fused_lars_(w, g, v, lowp, ratios, seg_offsets, seg_ends, lr, mu, wd, lr_scale=None) -> None:
     """K15 pass 2: v = mu*v + lr*ratio[k]*(g + wd*w); w -= v."""
     nseg = seg_ends.numel()

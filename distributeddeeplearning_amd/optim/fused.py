@@ -313,8 +313,8 @@ class FusedLARS(_ArenaOptimizer):
         from ..ops import kernels
 
         if self.arena.device.type == "cuda" and kernels.enabled():
-            wn, gn = kernels.segmented_norms(w[a:run["end"]], g[a:run["end"]],
-                                             run["seg_offsets"], run["seg_ends"])
+            return kernels.lars_trust_ratios(w[a:run["end"]], g[a:run["end"]], run["seg_offsets"], run["seg_ends"],
+                                             g0["trust_coefficient"], wd, g0["eps"])
         else:
             wn = torch.stack([w[s.offset: s.offset + s.numel].norm() for s in run["segments"]])
             gn = torch.stack([g[s.offset: s.offset + s.numel].float().norm()
@@ -357,7 +357,7 @@ class FusedLARS(_ArenaOptimizer):
             if hip:
                 lowp = self.arena.params[dt][a:b] if dt in self.master else None
                 klr, kscale = self._kernel_lr(lr)
-                kernels.fused_lars_(w[a:b], grads[a:b], v[a:b], lowp, ratios.contiguous(),
+                kernels.fused_lars_(w[a:b], grads[a:b], v[a:b], lowp, ratios,
                                     run["seg_offsets"], run["seg_ends"], klr, mu, run_wd, kscale)
                 continue
             for k, s in enumerate(run["segments"]):

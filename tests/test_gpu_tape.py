@@ -90,6 +90,19 @@ def test_taped_resnet50_with_learning_rate_schedule_equals_eager():
     _same(st_t, st_e)
 
 
+def test_taped_lars_step_has_no_framework_operators():
+    """FusedLARS: segment norms, trust ratios and the update are in-tree launches, so the large-batch recipe
+    (BASELINE config 4) replays from the tape as well.  The norms are summed with fp32 atomics (order not
+    fixed), so replayed and eager runs agree to rounding, not bit for bit."""
+    from distributeddeeplearning_amd.models import resnet18
+
+    s_e, l_e, _ = _run(resnet18, 32, 8, 64, 8, taped=False, opt="lars")
+    s_t, l_t, _ = _run(resnet18, 32, 8, 64, 8, taped=True, opt="lars")
+    assert s_t.taped and s_t.foreign_ops == {}, s_t.failed
+    assert max(abs(a - b) / max(abs(b), 1e-3) for a, b in zip(l_t, l_e)) < 2e-2, (l_t, l_e)
+    assert l_t[-1] < l_t[0]
+
+
 def test_a_step_with_framework_operators_is_refused_not_replayed():
     """A loss function that multiplies by a tensor runs an ATen kernel in forward and one in backward
     (on autograd's thread): a replay would skip both.  The watch must see them, the step must stay
