@@ -47,6 +47,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// One 16-byte-per-lane LDS-DMA (`buffer_load_dwordx4 ... lds`) issued from inline asm, i.e. invisible to
+// hipcc's wait-count insertion: the compiler orders LDS accesses it considers stores (the transposing
+// `ds_read_b64_tr_b16` builtin among them) behind ALL LDS-DMA it knows to be in flight with `s_waitcnt vmcnt(0)`,
+// which empties a multi-stage ring; hidden, the DMA is ordered by the kernel's own counted waits.
+// `lds_addr` (byte address of the wave's 1 KiB piece) and `soff` are wave-uniform; one wait state separates
+// the write of M0 from its use.  `rsrc`: raw buffer descriptor (raw_rsrc).
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // (already uniform: tells the compiler so)
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+
 static inline int ddl_launch_status_at(const char* file, int line) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) return DDL_OK;

@@ -84,6 +84,9 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 //        backward needs neither the mask tensor nor a masked copy of the gradient;
 //      4 = 3 plus the sum g / sum g*y partials of the BatchNorm that feeds that ReLU (ep_y), and
 //        with ep_y2 also those of the projection shortcut's BatchNorm (same g, other y).
+#ifndef DDL_CONV_STAGES
+#define DDL_CONV_STAGES 2
+#endif
 #ifndef DDL_CONV_MIN_WAVES
 #define DDL_CONV_MIN_WAVES 2   // waves per SIMD the register allocation must allow (3 and 4 measured: profiles/r1_notes.md)
 #endif
@@ -116,7 +119,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
     constexpr int OSTR = BN * 2 + 16;        // padded out-tile row stride (bytes)
     constexpr int SROWS = EPI == 4 ? 3 : 2;   // sums per channel kept by the epilogue
     constexpr int EPI_BYTES = BM * OSTR + 4 * SROWS * BN * 4;  // out tile + [4 waves][SROWS][BN] fp32 stats scratch
-    constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+    // LDS-DMA ring: NSTG stages, NSTG-1 tiles in flight across the barrier (counted vmcnt, raw s_barrier);
+    // 2 = one tile in flight, drained at every barrier (the round-1/2 loop)
+    constexpr int NSTG = (GLDS && BK == 32) ? DDL_CONV_STAGES : 2;
+    constexpr int LDS_BYTES = (NSTG * STAGE > EPI_BYTES) ? NSTG * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -172,6 +178,11 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
     x2_left = x2_left < 0 ? 0 : (x2_left > 0x7fffffffLL ? 0x7fffffffLL : x2_left);
     const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? p.x2 + (long long)m0 * p.C2 : p.x), 0, (int)x2_left, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? p.w2 : p.w), 0, DUAL ? (int)p.w2_bytes : 0, 0x00020000);
+    // raw twins for the LDS-DMA issued from inline asm (common.h::lds_dma16)
+    const u32x4 xq = raw_rsrc(p.x + x_first, (unsigned)x_left), wq = raw_rsrc(p.w, p.w_bytes);
+    const u32x4 xq2 = raw_rsrc(DUAL ? p.x2 + (long long)m0 * p.C2 : p.x, (unsigned)x2_left), wq2 = raw_rsrc(DUAL ? p.w2 : p.w, DUAL ? p.w2_bytes : 0u);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
 
     // GLDS (operand tiles by LDS-DMA, `buffer_load_dwordx4 ... lds`): a wave-instruction writes
     // 64 x 16 bytes at a wave-uniform LDS base + lane * 16, so the swizzle moves to the SOURCE side:
@@ -285,35 +296,31 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
 
     typedef __attribute__((address_space(3))) void* lds_void_ptr;
     auto fetch_lds = [&](int stage) {   // GLDS: global -> LDS without a register stop
+        const unsigned As = lds0 + (unsigned)(stage * STAGE + wid_u * (64 / CPR) * (BK * 2)), Bs = As + A_BYTES;
         if (DUAL && kfetch >= KT1) {        // second segment: plain rows of x2 / w2, C2 channels
             const int k2 = (kfetch - KT1) * (BK * 2);
-            unsigned char* As2 = smem + stage * STAGE + wid * (64 / CPR) * (BK * 2);
-            unsigned char* Bs2 = As2 + A_BYTES;
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr2, (lds_void_ptr)(As2 + i * RPP * (BK * 2)), 16, (int)a_voff2[DUAL ? i : 0], k2, 0, 0);
+                lds_dma16(xq2, As + i * RPP * (BK * 2), a_voff2[DUAL ? i : 0], (unsigned)k2);
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wr2, (lds_void_ptr)(Bs2 + i * RPP * (BK * 2)), 16, (int)b_off2[DUAL ? i : 0], k2, 0, 0);
+                lds_dma16(wq2, Bs + i * RPP * (BK * 2), b_off2[DUAL ? i : 0], (unsigned)k2);
             ++kfetch;
             return;
         }
         if (DUAL) ++kfetch;
         if (kc == 0) retap();
         const int kco = kc * (BK * 2);
-        unsigned char* As = smem + stage * STAGE + wid * (64 / CPR) * (BK * 2);
-        unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_ptr)(As + i * RPP * (BK * 2)), 16, (int)a_voff[i], kco, 0, 0);
+            lds_dma16(xq, As + i * RPP * (BK * 2), a_voff[i], (unsigned)kco);
         // WT: tap (kr, ks) of the backward conv is tap (R-1-kr, S-1-ks) of the forward filter
         const int wk = WT ? (kc * BK * RSN + ((p.R - 1 - kr) * p.S + (p.S - 1 - ks)) * p.N) * 2
                           : ((kr * p.S + ks) * p.C + kc * BK) * 2;
         const bool wlast = WT && kc == cpt - 1;   // uniform
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_ptr)(Bs + i * RPP * (BK * 2)), 16,
-                                                     (int)(wlast ? b_off_last[WT ? i : 0] : b_off[i]), wk, 0, 0);
+            lds_dma16(wq, Bs + i * RPP * (BK * 2), wlast ? b_off_last[WT ? i : 0] : b_off[i], (unsigned)wk);
         if (++kc == cpt) { kc = 0; ks += tstep; if (ks >= p.S) { ks = s0; kr += tstep; } }
     };
 
@@ -385,7 +392,30 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
     // workgroups per CU: profiles/r1_notes.md)
     u32x4 a0[A_LOADS], b0[B_LOADS];
     DDL_STAMP(1);
-    if (GLDS) {
+    if (GLDS && NSTG > 2) {
+        // ring: NSTG-1 tiles in flight; tile kt+1 is waited for with a COUNTED vmcnt that leaves the younger
+        // tiles in flight (every tile is A_LOADS + B_LOADS DMA instructions per thread), raw barrier; the last
+        // NSTG-1 iterations issue nothing and drain
+        constexpr int PRE = NSTG - 1, LPT = A_LOADS + B_LOADS, KEEP = (PRE - 1) * LPT;
+        static_assert(KEEP < 64, "vmcnt is a 6-bit counter");
+#pragma unroll
+        for (int s0_ = 0; s0_ < PRE; ++s0_)
+            if (s0_ < KT) fetch_lds(s0_);
+        if (KT >= PRE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0, nxt = PRE;
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool more = kt + PRE < KT;   // uniform
+            if (more) fetch_lds(nxt);
+            compute(cur);
+            if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(KEEP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            nxt = cur;
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
+        }
+    } else if (GLDS) {
         // two LDS buffers, the next tile's DMA in flight while this tile is consumed; the wait
         // before the barrier retires it (the barrier then publishes it to the other waves)
         if (KT > 0) fetch_lds(0);

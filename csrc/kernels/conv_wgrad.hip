@@ -48,20 +48,6 @@ __device__ __forceinline__ int lds_swz(int row) {
     return ROW_BYTES == 256 ? (row & 7) : ((row >> 1) & 3);
 }
 
-// One 16-byte-per-lane LDS-DMA, issued so that hipcc does not see it: the compiler orders every LDS read
-// after ALL LDS-DMA it knows to be in flight (`s_waitcnt vmcnt(0)` in front of the first ds_read of each
-// tile - seen in the .s of the builtin form), which empties the ring.  Hidden in inline asm, the DMA is
-// ordered by this kernel's own counted waits.  `lds_addr` (byte address of the wave's 1 KiB piece) and
-// `soff` are wave-uniform; one wait state separates the write of M0 from its use.
-__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-    return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-}
-
 template <int BMw, int BNw, bool SIMPLE, bool UNITAP, bool GLDS, int BK = 32>
 __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p) {
     static_assert(!GLDS || ((BMw == 64 || BMw == 128) && (BNw == 64 || BNw == 128)), "LDS-DMA image: 128- or 256-byte rows");
