@@ -24,6 +24,7 @@
 // per-channel sum / sum-of-squares partials for BatchNorm (K6 fused: saves one full read of y).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -544,26 +545,29 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; s3[e] = 0.f; }
     };
-#pragma unroll
-    for (int it0 = 0; it0 < OITER; it0 += BATCH) {
+    // FULL: the tile lies inside the problem (every tile of the training step's large layers): no edge
+    // predicates, no clamped addresses, no "live" multiplies in the sums - the epilogue of the short-reduction
+    // layers is bound by vector-instruction issue (profiles/r2_notes.md section 19)
+    auto rows = [&](auto full_c, int it0) {
+        constexpr bool FULL = decltype(full_c)::value;
         long long off[BATCH], aoff[BATCH];
         bool ok[BATCH], has[BATCH];
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
             int row = orow0 + (it0 + b) * ORPP, m = m0 + row;
-            ok[b] = (m < m_lim) & col_ok;
+            ok[b] = FULL ? true : ((m < m_lim) & col_ok);
             if (p.parity) {  // class-local row -> pixel row of the output image
                 int bb = m / hw, rem = m - bb * hw;
                 int hh = rem / Wq, wh = rem - hh * Wq;
                 m = (bb * p.Hout + 2 * hh + ph) * p.Wout + 2 * wh + pw;
             }
             long long o = (long long)m * p.N + n;
-            off[b] = ok[b] ? o : 0;
+            off[b] = (FULL || ok[b]) ? o : 0;
             has[b] = false; aoff[b] = 0;
             if (ADDEND) {
                 long long ao = o;
                 bool h = ok[b];
-                if (p.addend_sub2) {
+                if (!FULL && p.addend_sub2) {
                     int img = p.Hout * p.Wout;
                     int bb = m / img, rem = m - bb * img;
                     int hi = rem / p.Wout, wi = rem - hi * p.Wout;
@@ -571,6 +575,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
                     ao = ((long long)(bb * (p.Hout >> 1) + (hi >> 1)) * (p.Wout >> 1) + (wi >> 1)) * p.N + n;
                 }
                 has[b] = h; aoff[b] = h ? ao : 0;
+                if (FULL) { has[b] = true; aoff[b] = o; }   // (FULL launches have no sub-sampled addend)
             }
         }
         bf16x8 av[BATCH], zm[BATCH], yv[BATCH], y2v[BATCH];
@@ -611,13 +616,13 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
                     v[e] = keep ? v[e] : f2bf(0.f);
                 }
             }
-            const float live = ok[b] ? 1.f : 0.f;   // rows past the edge add nothing to the sums
+            const float live = (FULL || ok[b]) ? 1.f : 0.f;   // rows past the edge add nothing to the sums
             if (EPI == 4) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float g = bf2f(v[e]) * live; s1[e] += g; s2[e] += g * bf2f(yv[b][e]); }
+                for (int e = 0; e < 8; ++e) { float g = FULL ? bf2f(v[e]) : bf2f(v[e]) * live; s1[e] += g; s2[e] += g * bf2f(yv[b][e]); }
                 if (y2on) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s3[e] += bf2f(v[e]) * live * bf2f(y2v[b][e]);
+                    for (int e = 0; e < 8; ++e) s3[e] += (FULL ? bf2f(v[e]) : bf2f(v[e]) * live) * bf2f(y2v[b][e]);
                 }
             }
             if (EPI == 2) {
@@ -627,7 +632,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
                     bool on = bn_affine(yf, fsc[e], fsh[e]) > 0.f;
                     v[e] = on ? v[e] : f2bf(0.f);
                     float g = bf2f(v[e]);
-                    if (DUAL) g *= live;   // (without the bias of the two-segment form rows past the edge are exact zeros)
+                    if (DUAL && !FULL) g *= live;   // (without the bias of the two-segment form rows past the edge are exact zeros)
                     s1[e] += g; s2[e] += g * yf;
                 }
             }
@@ -637,8 +642,14 @@ __global__ void __launch_bounds__(256, (BM == 128 && BK == 32) ? DDL_CONV_MIN_WA
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { float f = bf2f(v[e]); s1[e] += f; s2[e] += f * f; }
             }
-            if (ok[b]) *reinterpret_cast<bf16x8*>(p.y + off[b]) = v;
+            if (FULL || ok[b]) *reinterpret_cast<bf16x8*>(p.y + off[b]) = v;
         }
+    };
+    const bool full_tile = (m0 + BM <= m_lim) && (n0 + BN <= p.N) && !(ADDEND && p.addend_sub2);   // uniform
+#pragma unroll
+    for (int it0 = 0; it0 < OITER; it0 += BATCH) {
+        if (full_tile) rows(std::true_type{}, it0);
+        else rows(std::false_type{}, it0);
         if (STATS && (it0 + BATCH) % SUB_ITERS == 0) emit_stats((it0 + BATCH) / SUB_ITERS - 1);
     }
 #ifdef DDL_CONV_PROBES
