@@ -247,7 +247,7 @@ def _i32(v):
     return ctypes.c_int(int(v))
 
 
-# timing probe (scripts/gpu_r3_probe.sh): DDL_PROBE_SKIP_WGRAD=all|late|early drops the weight-gradient GEMMs
+# timing probe (scripts/gpu_r3_probe.sh): DDL_PROBE_SKIP_WGRAD=all|late|early drops the weight-gradient GEMMs, =reduce the plain slab reductions
 _PROBE_SKIP_WGRAD = os.environ.get("DDL_PROBE_SKIP_WGRAD", "")
 
 # diagnostic: a list that receives one tuple per conv launch (scripts/conv_roofline.py); None = off
@@ -339,7 +339,7 @@ def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hou
                stream=None):
     """``partial``: tensor or raw address; ``stream``: raw HIP stream (default: current)."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
-    if _PROBE_SKIP_WGRAD and (_PROBE_SKIP_WGRAD == "all" or (_PROBE_SKIP_WGRAD == "late") == (Hout <= 14)):
+    if _PROBE_SKIP_WGRAD == "all" or (_PROBE_SKIP_WGRAD == "late" and Hout <= 14) or (_PROBE_SKIP_WGRAD == "early" and Hout > 14):
         return   # timing probe only (gradients are garbage): what the step costs without these launches
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append(("conv_wgrad", B, Hin, Win, C, Hout, Wout, K, R, S, stride, 1, dy.numel() // K, splits))
@@ -351,6 +351,8 @@ def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hou
 
 def splitk_reduce(partial, out, n, splits, slab, accumulate=False, stream=None, out_bf16=None):
     """``out``: tensor, or a raw address with ``out_bf16`` saying what it holds."""
+    if _PROBE_SKIP_WGRAD == "reduce":
+        return   # timing probe only
     f = _fn("ddl_splitk_reduce", "pp qiq ii p")
     if out_bf16 is None:
         out_bf16 = out.dtype == torch.bfloat16
