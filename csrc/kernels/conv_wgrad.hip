@@ -525,6 +525,180 @@ __global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p)
         }
 }
 
+// ---- 3x3 / stride 1 / pad 1 layers with 64 or 128 channels: row-streaming kernel ------------------
+// The 64- and 128-channel 3x3 weight gradients ran at 490-690 TFLOP/s in the tile kernel: one tap and 64 x 64
+// outputs per workgroup means 4 MFMAs per wave between two DMA round trips, and every tap re-fetches dy and x.
+// Here a workgroup (8 waves) owns ALL nine taps of 64 output channels: the whole [64][9*C] partial lives in its
+// accumulators (72 / 144 registers per lane) and it streams its images row by row.  A step is RS output rows
+// (RS * W = 56 pixels, zero-padded to 64 = two MFMA reduction steps); its LDS stage holds the RS + 2 input rows
+// the nine taps read, each with a ZERO halo pixel on both sides and zero rows above / below the image (written by
+// the DMA's range check: no masks, no bounds arithmetic in the loop), plus the dy rows.  Tap (r, s) of pixel
+// (row rr, column w) is LDS row rr + r, pixel w + s: 36 / 72 MFMAs per wave and step against 5 / 6 DMA pieces.
+// Stages form the same ring as above (DMA of step t+2 in flight while step t is multiplied; counted vmcnt).
+// Wave grid 2 (halves of the 64 output channels) x 4 (16-channel groups of C): every wave sees all nine taps,
+// so tap offsets are compile-time immediates.  Pad pixels (56..63) have dy = 0 (range check) and read a clamped,
+// finite x pixel.  Swizzle: 32-byte window w of pixel P at window w ^ f(P), f = (P >> 1) & 3 for 128-byte
+// pixels, P & 7 for 256-byte pixels (as in the tile kernels), applied to the DMA source and to the reads.
+template <int C, int RS>
+__global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams p, int imgs_per_split, int B) {
+    constexpr int XB = C * 2, XW = XB / 32, CF = C / 16, CL = CF / 4;
+    constexpr int NST = 3, XROWS = RS + 2, DYOFF = XROWS * 8192, STAGE = DYOFF + 8192, NP = XROWS + 1;
+    static_assert(C == 64 || C == 128, "16-channel groups over four waves");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid >> 2, wc = wid & 3;
+    const int khalves = p.K / 64;
+    const int nwg = p.splits * khalves;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int split = bid / khalves, kh = bid - split * khalves;
+    const int H = p.Hout, W = p.Wout, RSC = 9 * C;
+    const int b_begin = split * imgs_per_split;
+    int b_end = b_begin + imgs_per_split;
+    if (b_end > B) b_end = B;
+    const int SPI = H / RS;                       // steps per image
+    const int T = (b_end - b_begin) * SPI;
+
+    const u32x4 dyr = raw_rsrc(p.dy, (unsigned)p.dy_bytes), xr = raw_rsrc(p.x, (unsigned)p.x_bytes);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    constexpr unsigned INVALID = 0x80000000u;
+
+    // this lane's 16 bytes of its wave's 1 KiB DMA piece: an x row slot is 8 KiB (8192 / XB pixels, pixel 0 = the
+    // left halo), the dy tile 64 pixels x 128 bytes (this workgroup's 64 output channels)
+    unsigned x_lane, dy_lane;
+    {
+        const int byte = wid * 1024 + lane * 16;
+        const int P = byte / XB, chp = (byte % XB) >> 4;
+        const int fx = XB == 128 ? ((P >> 1) & 3) : (P & 7);
+        const int lch = ((((chp >> 1) ^ fx)) << 1) | (chp & 1);
+        const int w = P - 1;
+        x_lane = (w >= 0 && w < W) ? (unsigned)((w * C + lch * 8) * 2) : INVALID;
+        const int m = byte >> 7, dchp = (byte & 127) >> 4;
+        const int dlch = ((((dchp >> 1) ^ ((m >> 1) & 3))) << 1) | (dchp & 1);
+        dy_lane = (m < RS * W) ? (unsigned)((m * p.K + dlch * 8) * 2) : INVALID;
+    }
+    // every step is exactly NP DMA instructions per wave (steps past the end and rows outside the image read zeros)
+    auto fetch = [&](int t, int stage) {
+        const bool live = t < T;
+        const int tt = live ? t : 0;
+        const int b = b_begin + tt / SPI, h0 = (tt % SPI) * RS;
+        const unsigned sb = lds0 + (unsigned)(stage * STAGE + wid * 1024);
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            const int hin = h0 - 1 + i;
+            const bool ok = live && hin >= 0 && hin < H;     // uniform
+            const unsigned soff = ok ? (unsigned)(((b * H + hin) * W) * C) * 2u : 0u;
+            lds_dma16(xr, sb + i * 8192, ok ? x_lane : INVALID, soff);
+        }
+        const unsigned dsoff = (unsigned)(((b * H + h0) * W) * p.K + kh * 64) * 2u;
+        lds_dma16(dyr, sb + DYOFF, live ? dy_lane : INVALID, dsoff);
+    };
+    auto wait_steps = [&](int steps_in_flight) {
+        if (steps_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
+        else if (steps_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // transposing-read lane geometry: lane 16g + 4q + pq supplies reduction row 4g + q (+16), bytes 8pq..8pq+7 of a window
+    const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+    const int tr_row = 4 * g + q;
+    // dy fragments (rows = pixels of the step, 128-byte rows): [reduction step][16-channel group of this wave's half]
+    int a_off[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = ks * 32 + tr_row;
+            a_off[ks][i] = DYOFF + row * 128 + (((wn * 2 + i) ^ ((row >> 1) & 3)) << 5) + 8 * pq;   // second half: + 16 rows (same swizzle)
+        }
+    // x fragments: [reduction step][half][s][channel group]: pixel w + s of row rr (tap row r adds r * 8192 as an immediate)
+    int x_off[2][2][3][CL];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            int m = ks * 32 + tr_row + 16 * hf;
+            if (m > RS * W - 1) m = RS * W - 1;          // pad pixels: dy is zero there, x only has to be finite
+            const int rr = m / W, w = m - rr * W;
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const int P = w + s_;
+                const int fx = XB == 128 ? ((P >> 1) & 3) : (P & 7);
+#pragma unroll
+                for (int cl = 0; cl < CL; ++cl)
+                    x_off[ks][hf][s_][cl] = rr * 8192 + P * XB + ((((wc * CL + cl) ^ fx)) << 5) + 8 * pq;
+            }
+        }
+
+    f32x4 acc[2][9][CL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int cl = 0; cl < CL; ++cl) acc[i][t9][cl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0, 0);
+    fetch(1, 1);
+    wait_steps(1);
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = 2;
+    for (int t = 0; t < T; ++t) {
+        fetch(t + 2, nxt);
+        const unsigned char* St = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + a_off[ks][i]));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + a_off[ks][i] + 16 * 128));
+                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int r_ = t9 / 3, s_ = t9 - 3 * r_;
+#pragma unroll
+                for (int cl = 0; cl < CL; ++cl) {
+                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + x_off[ks][0][s_][cl] + r_ * 8192));
+                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + x_off[ks][1][s_][cl] + r_ * 8192));
+                    const bf16x8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][t9][cl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][t9][cl], 0, 0, 0);
+                }
+            }
+        }
+        wait_steps(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        nxt = cur;
+        cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // D rows = output channel (4 per lane), cols = (tap, channel) (lane & 15)
+    float* out = p.partial + (long long)split * p.K * RSC;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int cl = 0; cl < CL; ++cl) {
+                const int jc = t9 * C + (wc * CL + cl) * 16 + fr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = kh * 64 + wn * 32 + i * 16 + fq * 4 + e;
+                    out[(long long)n * RSC + jc] = acc[i][t9][cl][e];
+                }
+            }
+}
+
 // out[i] = sum_s partial[s][i] (fixed order => deterministic), bf16 or fp32 output.
 // Block = (256 / SL) float4 columns x SL split lanes, so that tall-and-narrow reductions (a 64x64
 // 1x1 conv weight summed over 512 slabs) still spread over many CUs with short dependent chains.
@@ -713,6 +887,34 @@ static int wgrad_big_splits(long long M, int K, int C, int R, int S) {
     return (int)want;
 }
 
+// The row-streaming kernel: 3x3 / stride 1 / pad 1 on 56- or 28-pixel rows with 64 or 128 input channels.
+// DDL_WGRAD_ROWS=0|1; DDL_WGRAD_ROWS_TARGET = workgroups to aim for (images are dealt out whole).
+static bool wgrad_rows(int K, int C, int R, int S, int Hout, int Wout, int stride, int B) {
+    static const int on = getenv("DDL_WGRAD_ROWS") ? atoi(getenv("DDL_WGRAD_ROWS")) : 1;  // tuning knob
+    if (!on || R != 3 || S != 3 || stride != 1 || B <= 0) return false;
+    if (!(C == 64 || C == 128) || K % 64 != 0) return false;
+    if (!(Wout == 56 || Wout == 28)) return false;
+    const int rs = 56 / Wout;
+    return Hout % rs == 0;
+}
+static int wgrad_rows_ips(int K, int B) {
+    static const int target = getenv("DDL_WGRAD_ROWS_TARGET") ? atoi(getenv("DDL_WGRAD_ROWS_TARGET")) : 256;  // tuning knob
+    int nsplit = target / (K / 64);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > B) nsplit = B;
+    return (B + nsplit - 1) / nsplit;
+}
+
+extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S);
+// `Hout`, `Wout`, `stride`, `B` (0 when the caller does not know them: a plain GEMM) select the row-streaming kernel
+extern "C" int ddl_conv_wgrad_splits_ex(long long M, int K, int C, int R, int S, int Hout, int Wout, int stride, int B) {
+    if (wgrad_rows(K, C, R, S, Hout, Wout, stride, B)) {
+        const int ips = wgrad_rows_ips(K, B);
+        return (B + ips - 1) / ips;
+    }
+    return ddl_conv_wgrad_splits(M, K, C, R, S);
+}
+
 extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S) {
     if (wgrad_big(M, K, C, R, S)) return wgrad_big_splits(M, K, C, R, S);
     int bm, bn;
@@ -769,6 +971,18 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
     if ((mps / ((long long)Hout * Wout) + 3) * xs_b * 2 >= 0x7fffffffLL || (mps + 64) * xs_w * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0 && pad_w == 0 && Hin == Hout && Win == Wout &&
                 xs_h == (long long)Win * xs_w && xs_b == (long long)Hin * xs_h) ? 1 : 0;
+    if (wgrad_rows(K, C, R, S, Hout, Wout, stride, B) && pad == 1 && pad_w == 1 && Hin == Hout && Win == Wout &&
+        xs_w == C && xs_h == (long long)Win * C && xs_b == (long long)Hin * Win * C &&
+        p.dy_bytes < 0x7fffffffLL && p.x_bytes < 0x7fffffffLL) {
+        const int ips = wgrad_rows_ips(K, B);
+        if (splits != (B + ips - 1) / ips) return DDL_EINVAL;   // the workspace was sized by ddl_conv_wgrad_splits_ex
+        dim3 grid(splits * (K / 64)), block(512);
+        if (C == 64 && Wout == 56) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1>), grid, block, 0, stream, p, ips, B);
+        else if (C == 64) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 2>), grid, block, 0, stream, p, ips, B);
+        else if (Wout == 56) DDL_KLAUNCH((conv_wgrad_rows_kernel<128, 1>), grid, block, 0, stream, p, ips, B);
+        else DDL_KLAUNCH((conv_wgrad_rows_kernel<128, 2>), grid, block, 0, stream, p, ips, B);
+        return ddl_launch_status();
+    }
     if (wgrad_big(M, K, C, R, S)) {
         static const int nst = getenv("DDL_WGRAD_BIG_NST") ? atoi(getenv("DDL_WGRAD_BIG_NST")) : 3;  // tuning knob
         p.tiles_k = K / 256;

@@ -195,7 +195,7 @@ def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho
     current stream nor allocates."""
     B, Hin, Win, C = geom[0], geom[1], geom[2], geom[3]
     M = B * Ho * Wo
-    splits = K.conv_wgrad_splits(M, Kc, C, R, S)
+    splits = K.conv_wgrad_splits(M, Kc, C, R, S, Ho, Wo, stride, B)
     slab = Kc * R * S * C
     if workspace is None:
         partial = torch.empty((splits, slab), dtype=torch.float32, device=dy.device)

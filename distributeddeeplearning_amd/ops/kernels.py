@@ -331,8 +331,12 @@ def conv_tiles_m_bwd(M, Hout, Wout, idil, ostride):
 
 
 @functools.lru_cache(maxsize=None)
-def conv_wgrad_splits(M, K, C, R, S):
-    return int(lib().ddl_conv_wgrad_splits(_i64(M), _i32(K), _i32(C), _i32(R), _i32(S)))
+def conv_wgrad_splits(M, K, C, R, S, Hout=0, Wout=0, stride=1, B=0):
+    """Reduction splits (= fp32 partial slabs) the weight-gradient launch of this problem writes.  ``Hout`` /
+    ``Wout`` / ``stride`` / ``B`` let the library pick the row-streaming 3x3 kernel (it deals out whole images);
+    a launch must be planned with the same values it is then called with."""
+    return int(lib().ddl_conv_wgrad_splits_ex(_i64(M), _i32(K), _i32(C), _i32(R), _i32(S), _i32(Hout), _i32(Wout),
+                                              _i32(stride), _i32(B)))
 
 
 def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hout, Wout, splits,
