@@ -642,36 +642,53 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams 
 #pragma unroll
             for (int cl = 0; cl < CL; ++cl) acc[i][t9][cl] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // fragments of half a step (32 pixels, all nine taps) live in registers, so that reading them and multiplying
+    // them can be separate PHASES
+    bf16x8 af[2], bfr[9][CL];
+    auto read_frags = [&](const unsigned char* St, int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ao = ks ? a_off[1][i] : a_off[0][i];
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + ao));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + ao + 16 * 128));
+            af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            const int r_ = t9 / 3, s_ = t9 - 3 * r_;
+#pragma unroll
+            for (int cl = 0; cl < CL; ++cl) {
+                const int o0 = ks ? x_off[1][0][s_][cl] : x_off[0][0][s_][cl], o1 = ks ? x_off[1][1][s_][cl] : x_off[0][1][s_][cl];
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + o0 + r_ * 8192));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + o1 + r_ * 8192));
+                bfr[t9][cl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    };
+    auto mfma_all = [&]() {
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int cl = 0; cl < CL; ++cl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i][t9][cl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[t9][cl], acc[i][t9][cl], 0, 0, 0);
+    };
+
     fetch(0, 0);
     fetch(1, 1);
     wait_steps(1);
     __builtin_amdgcn_s_barrier();
     int cur = 0, nxt = 2;
+    // (Measured and dropped, profiles/r3_notes.md: a two-phase schedule with the two waves of a SIMD one phase
+    // apart - one reads fragments while the other multiplies - 75 -> 95 us; the second wave group issuing its DMA
+    // pieces between the two reduction halves instead of at the top of the step, 75.6 -> 78.5 us.)
     for (int t = 0; t < T; ++t) {
         fetch(t + 2, nxt);
-        const unsigned char* St = smem + cur * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + a_off[ks][i]));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + a_off[ks][i] + 16 * 128));
-                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9) {
-                const int r_ = t9 / 3, s_ = t9 - 3 * r_;
-#pragma unroll
-                for (int cl = 0; cl < CL; ++cl) {
-                    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + x_off[ks][0][s_][cl] + r_ * 8192));
-                    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(St + x_off[ks][1][s_][cl] + r_ * 8192));
-                    const bf16x8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        acc[i][t9][cl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][t9][cl], 0, 0, 0);
-                }
-            }
+            read_frags(smem + cur * STAGE, ks);
+            mfma_all();
         }
         wait_steps(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
