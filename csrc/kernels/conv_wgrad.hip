@@ -30,6 +30,11 @@ struct WgradParams {
     int R, S, stride, pad, pad_w;
     int tiles_k, tiles_rsc, splits, m_per_split;  // tiles over K and over the flattened (r, s, c) axis
     int simple;  // x row of pixel m is x + m*xs_w (1x1, stride 1, no padding)
+    // Interleaved reduction ranges (plain GEMMs, 0 = off): the reduction rows are cut into 8 groups of il_mg
+    // rows (one per XCD, as the backward-data kernel's tile order cuts them) and the il_sg splits of a group
+    // take its 32/64-row tiles round-robin, so the whole grid sweeps every group front to back - the
+    // order in which the backward-data kernel running next to it reads the same two tensors
+    int il_sg, il_mg;
 };
 
 __device__ __forceinline__ u32x4 wg_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -81,10 +86,17 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     const int n0 = tile_k * BMw, j0 = tile_j * BNw;
     const int RSC = p.R * p.S * p.C;
 
-    const int m_begin = split * p.m_per_split;
+    int m_begin = split * p.m_per_split;
     int m_end = m_begin + p.m_per_split;
+    int kstep = 1;                       // tiles from one tile of this split to its next
+    if (SIMPLE && p.il_sg > 0) {
+        const int grp = split / p.il_sg, j = split - grp * p.il_sg;
+        m_begin = grp * p.il_mg + j * BK;
+        m_end = (grp + 1) * p.il_mg;
+        kstep = p.il_sg;
+    }
     if (m_end > p.M) m_end = p.M;
-    const int KT = (m_end - m_begin + BK - 1) / BK;
+    const int KT = m_begin < m_end ? (m_end - m_begin + kstep * BK - 1) / (kstep * BK) : 0;
 
     // Tensors beyond 2 GiB: the descriptors start at this split's first reduction row (dy; x of a
     // plain GEMM) or first image (x), so 32-bit offsets only span one split.
@@ -154,6 +166,7 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     // GLDS: the tile goes global -> LDS by LDS-DMA; chunk idx = tid + i*256 of the dense image lands
     // at byte idx*16, i.e. wave base (wid*64 + i*256)*16 + lane*16
     auto fetch = [&](int kt, int stage) {
+        kt *= kstep;
         const int rows_left = m_end - (m_begin + kt * BK);
         const int a_soff = kt * (BK * 2) * p.K;
         const unsigned Ad = lds0 + (unsigned)(stage * STAGE + wid_u * 1024), Bd = Ad + A_BYTES;
@@ -983,6 +996,7 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
     long long mps = (M + splits - 1) / splits;
     mps = (mps + 31) / 32 * 32;
     p.m_per_split = (int)mps;
+    p.il_sg = p.il_mg = 0;
     // 32-bit offsets inside one split: its dy rows, and the images its x rows come from
     if ((mps + 64) * K * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     if ((mps / ((long long)Hout * Wout) + 3) * xs_b * 2 >= 0x7fffffffLL || (mps + 64) * xs_w * 2 >= 0x7fffffffLL) return DDL_EINVAL;
@@ -1019,6 +1033,19 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
     }
     int bm, bn;
     wgrad_tile(K, C, R, S, bm, bn);
+    {
+        // DDL_WGRAD_INTERLEAVE = smallest reduction length (rows) that gets the interleaved order; 0 = never.
+        // Off by default: with it the stage 1-2 weight gradients sweep their operands in the backward-data
+        // kernel's order (hoping for Infinity Cache hits on the shared tensors) - 17.13 / 17.14 ms per step
+        // against 17.10 / 17.12 without (profiles/r3_notes.md section 12)
+        static const long long il_min = getenv("DDL_WGRAD_INTERLEAVE") ? atoll(getenv("DDL_WGRAD_INTERLEAVE")) : 0;  // tuning knob
+        const long long mg = ((M + 7) / 8 + 63) / 64 * 64;
+        if (il_min > 0 && p.simple && M >= il_min && splits % 8 == 0 && (mg + 128) * K * 2 < 0x7fffffffLL &&
+            (mg + 128) * xs_w * 2 < 0x7fffffffLL) {
+            p.il_sg = splits / 8;
+            p.il_mg = (int)mg;
+        }
+    }
     if (bm == 64) {
         if (bn == 32) return launch_wgrad<64, 32>(p, stream);
         if (bn == 64) return launch_wgrad<64, 64>(p, stream);

@@ -58,6 +58,8 @@ CONV_CASES = [
     (3, 64, 10, 12, 128, 1, 2, 0),    # 1x1 stride 2, parity dgrad with empty tap classes
     (65, 128, 28, 27, 256, 3, 1, 1),  # 256x128 block tile (N >= 256, R*S*C >= 1024, >= 384 tiles), ragged last tile
     (96, 1024, 23, 23, 256, 1, 1, 0), # 256x128 tile, 1x1 (fwd); its dgrad (N = 1024, C = 256) stays on 128x128
+    (33, 64, 56, 56, 256, 1, 1, 0),   # weight gradient over > 100 000 rows: interleaved reduction ranges, ragged last group
+    (33, 256, 56, 56, 64, 1, 1, 0),   # the same with the wide side as the input
 ]
 
 
