@@ -1,0 +1,279 @@
+// K1r: 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels on 56-pixel rows (the
+// middle conv of ResNet's first stage, forward and backward-data), as a ROW-STREAMING kernel (gfx950).
+//
+// In the tile kernel (conv_igemm.hip) this layer is nine 64-deep reduction steps per 128 x 64 tile: every
+// step fetches a fresh copy of its input pixels (9x the tensor through L2 -> LDS) and one tap of the filter,
+// does 16 MFMAs per wave and meets at a barrier; three workgroups per CU take turns waiting for DMA
+// (114 us forward for 59 GFLOP and 206 MB; profiles/r3_conv_roofline_v2.txt).  Here
+//   * a workgroup (8 waves) owns ONE IMAGE and walks down its rows, two output rows per step;
+//   * the filter never touches LDS: wave (nh, mg) keeps the [32 output channels][9 taps][64 channels] slice of
+//     its half nh in 144 registers for the whole image (MFMA A operand, D rows = output channels);
+//   * input rows go global -> LDS exactly once, by LDS-DMA, into a ring of row slots (64 pixels x 128 bytes: pixel
+//     0 and pixels 57.. are the zero halo, written by the DMA's range check; rows above / below the image
+//     likewise), DEPTH steps ahead, waited for with counted `vmcnt` and one barrier per step;
+//   * tap (r, s) of output pixel (row, w) is slot row + r, pixel w + s: the MFMA B operand is one 16-byte LDS
+//     read per lane (16 pixels x 32 channels per fragment), each fragment feeds the two output rows that see its
+//     input row and both 16-channel tiles: 72 MFMAs per 24 LDS reads per wave and step;
+//   * D columns are pixels and D rows channels, so a lane holds 4 consecutive channels of one pixel: the epilogue
+//     stores 8 bytes per lane straight from the accumulators - no LDS staging of the output tile.
+// Every vector-memory instruction of the loop (DMA, output stores) is inline asm: hipcc's wait-count insertion
+// never sees one and never drains the ring with `vmcnt(0)`; stores only make the counted waits stricter
+// (loads return in order among themselves, stores do not return in order with loads).
+//
+// BWD = the backward-data form whose output is the gradient of relu(bn(y_prev)) (conv_igemm's EPI 2): the rows
+// of y_prev ride in a second DMA ring, the epilogue masks with scale*y+shift > 0 and keeps sum g / sum g*y.
+// Statistics come out as ONE row per image ([B][2][64]): the finalize kernels sum any number of rows.
+#include "common.h"
+
+namespace {
+
+struct RowsParams {
+    const bf16_t* x;        // [B][H][56][64]
+    const bf16_t* w;        // [64][3][3][64]  (backward-data: the flipped / transposed filter, same layout)
+    bf16_t* y;              // [B][H][56][64]
+    float* stats;           // [B][2][64] or null
+    const bf16_t* ep_y;     // BWD: [B][H][56][64]
+    const float* ep_fcoef;  // BWD: [2][64] forward scale | shift
+    int B, H;
+    unsigned bytes;         // of one activation tensor
+};
+
+__device__ __forceinline__ void gstore8(u32x4 rsrc, unsigned voff, unsigned soff, u32x2 v) {
+    soff = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <bool BWD>
+__global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
+    constexpr int W = 56, C = 64, DEPTH = 3;
+    constexpr int NSX = 2 * DEPTH + 2, NSY = DEPTH + 1;          // x row slots; y groups (two rows each)
+    constexpr int SLOT = 8192, XBYTES = NSX * SLOT + 256;         // + 256: the last tile's tap reads run 2 pixels past its slot
+    constexpr int YBASE = XBYTES, YBYTES = BWD ? NSY * 2 * SLOT : 0;
+    constexpr int FBASE = YBASE + YBYTES, FBYTES = BWD ? 512 : 0;
+    constexpr int NPW = BWD ? 4 : 2;                              // DMA instructions per wave and step
+    constexpr unsigned INVALID = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FBASE + FBYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nh = wid >> 2, mg = wid & 3;
+    const int col = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x, H = p.H, T = H >> 1;
+
+    const u32x4 xr = raw_rsrc(p.x, p.bytes), yr = raw_rsrc(p.y, p.bytes);
+    const u32x4 er = raw_rsrc(BWD ? p.ep_y : p.x, p.bytes);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+
+    // ---- the filter slice of this wave: [tap][channel half][16-channel tile] fragments, A operand
+    //      (lane: row = output channel col of the tile, 8 reduction channels 32h + 8g ..)
+    bf16x8 wreg[9][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wreg[tap][h][j] = *reinterpret_cast<const bf16x8*>(p.w + ((32 * nh + 16 * j + col) * 9 + tap) * C + 32 * h + 8 * g);
+    if (BWD && tid < 128) reinterpret_cast<float*>(smem + FBASE)[tid] = p.ep_fcoef[tid];
+
+    // ---- DMA geometry.  A wave moves pieces q0, q0+1 (8 pixels each) of row (wid >> 2) of the step's two rows.
+    //      x: LDS pixel j = image column j - 1; 16-byte chunk c of pixel j sits at chunk c ^ ((j >> 1) & 7)
+    //      (16 consecutive pixels of one fragment read: conflict-free), applied here on the source address.
+    const int r2 = wid >> 2, q0 = 2 * (wid & 3);
+    unsigned xv[2], yv_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = 8 * (q0 + i) + (lane >> 3), cp = lane & 7;
+        const int ch = cp ^ ((j >> 1) & 7), xcol = j - 1;
+        xv[i] = (xcol >= 0 && xcol < W) ? (unsigned)(xcol * 128 + ch * 16) : INVALID;
+        yv_off[i] = (q0 + i) < 7 ? (unsigned)((q0 + i) * 1024 + lane * 16) : INVALID;     // 56 pixels = 7 pieces, linear
+    }
+    // group k: x rows v = 2k+2, 2k+3 (v = image row + 1; v = 0 and v = H+1 are zero rows) and, BWD, the y rows of step k
+    auto issue = [&](int k) {
+        const int v = 2 * k + 2 + r2;
+        const bool ok = v >= 1 && v <= H;                                   // uniform
+        const unsigned soff = ok ? (unsigned)((b * H + v - 1) * W) * 128u : 0u;
+        const unsigned dst = lds0 + (unsigned)(((v + NSX * 4) % NSX) * SLOT + q0 * 1024);
+        lds_dma16(xr, dst, ok ? xv[0] : INVALID, soff);
+        lds_dma16(xr, dst + 1024, ok ? xv[1] : INVALID, soff);
+        if (BWD) {
+            const int row = 2 * k + r2;
+            const bool yok = row >= 0 && row < H;
+            const unsigned ysoff = yok ? (unsigned)((b * H + row) * W) * 128u : 0u;
+            const unsigned yd = lds0 + (unsigned)(YBASE + ((k + NSY * 4) % NSY) * 2 * SLOT + r2 * SLOT + q0 * 1024);
+            lds_dma16(er, yd, yok ? yv_off[0] : INVALID, ysoff);
+            lds_dma16(er, yd + 1024, yok ? yv_off[1] : INVALID, ysoff);
+        }
+    };
+
+    // ---- fragment read offsets inside a row slot: [s][channel half]
+    int xo[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int j = 16 * mg + col + s;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xo[s][h] = j * 128 + (((4 * h + g) ^ ((j >> 1) & 7)) << 4);
+    }
+    // ---- epilogue geometry: this lane's pixel and its 4 channels per 16-channel tile
+    const int px = 16 * mg + col;
+    const bool pvalid = px < W;
+    unsigned ov[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ov[j] = pvalid ? (unsigned)((px * C + 32 * nh + 16 * j + 4 * g) * 2) : INVALID;
+
+    // the filter registers are complete BEFORE the loop: hipcc would otherwise wait for them (`vmcnt(0)`) at their
+    // first use inside it, on every iteration, and empty the DMA ring
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+        asm volatile("" : "+v"(wreg[tap][0][0]), "+v"(wreg[tap][0][1]), "+v"(wreg[tap][1][0]), "+v"(wreg[tap][1][1]));
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1[2][4], s2[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[j][e] = 0.f; s2[j][e] = 0.f; }
+
+    // ---- prologue: rows v = 0, 1 (half a group), then groups 0 .. DEPTH-1
+    {
+        const int v = r2;
+        const bool ok = v >= 1;
+        const unsigned soff = ok ? (unsigned)((b * H + v - 1) * W) * 128u : 0u;
+        const unsigned dst = lds0 + (unsigned)(v * SLOT + q0 * 1024);
+        lds_dma16(xr, dst, ok ? xv[0] : INVALID, soff);
+        lds_dma16(xr, dst + 1024, ok ? xv[1] : INVALID, soff);
+    }
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) issue(k);
+    wait_vm<(DEPTH - 1) * NPW>();           // rows 0..3 (and the y rows of step 0) have landed
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < T; ++t) {
+        // ---- multiply: input row i of the step (v = 2t + i) feeds output row o with tap row r = i - o
+        const int v0 = 2 * t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned char* row = smem + ((v0 + i) % NSX) * SLOT;
+            bf16x8 f[3][2];
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) f[s][h] = *reinterpret_cast<const bf16x8*>(row + xo[s][h]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int r = i - o;
+                if (r < 0 || r > 2) continue;
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[o][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[r * 3 + s][h][j], f[s][h], acc[o][j], 0, 0, 0);
+            }
+        }
+        // ---- group t+1 has landed (everywhere, after the barrier) and everybody is done with rows 2t, 2t+1
+        wait_vm<(DEPTH - 2) * NPW>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(t + DEPTH);
+
+        // ---- epilogue of step t: 4 channels of one pixel per lane and tile
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const unsigned soff = (unsigned)((b * H + 2 * t + o) * W) * 128u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x4 v;
+                if (BWD) {
+                    const int ch0 = 32 * nh + 16 * j + 4 * g;
+                    const bf16x4 yv = *reinterpret_cast<const bf16x4*>(smem + YBASE + (t % NSY) * 2 * SLOT + o * SLOT + px * 128 + ch0 * 2);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + FBASE + ch0 * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(smem + FBASE + 256 + ch0 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yf = bf2f(yv[e]);
+                        const bool on = bn_affine(yf, sc[e], sh[e]) > 0.f;
+                        v[e] = on ? f2bf(acc[o][j][e]) : f2bf(0.f);
+                        const float gg = pvalid ? bf2f(v[e]) : 0.f;
+                        s1[j][e] += gg; s2[j][e] += gg * yf;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = f2bf(acc[o][j][e]);
+                        const float f = pvalid ? bf2f(v[e]) : 0.f;
+                        s1[j][e] += f; s2[j][e] += f * f;
+                    }
+                }
+                gstore8(yr, ov[j], soff, __builtin_bit_cast(u32x2, v));
+                acc[o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    wait_vm<0>();
+    if (p.stats == nullptr) return;
+
+    // ---- statistics of the image: fold the 16 pixel lanes, then the four pixel groups (fixed order)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s1[j][e] += __shfl_xor(s1[j][e], o, 64);
+                s2[j][e] += __shfl_xor(s2[j][e], o, 64);
+            }
+    __syncthreads();                              // all waves are past their last LDS read
+    float* red = reinterpret_cast<float*>(smem);  // [2][4 pixel groups][64 channels]
+    if (col == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = 32 * nh + 16 * j + 4 * g + e;
+                red[mg * 64 + ch] = s1[j][e];
+                red[256 + mg * 64 + ch] = s2[j][e];
+            }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, ch = tid & 63;
+        const float* r = red + which * 256 + ch;
+        p.stats[((long long)b * 2 + which) * 64 + ch] = (r[0] + r[64]) + (r[128] + r[192]);
+    }
+}
+
+}  // namespace
+
+// Shapes the row-streaming kernel serves (DDL_CONV_ROWS=0 switches it off: the tile kernel then takes them)
+extern "C" int ddl_conv_rows3x3_ok(int C, int N, int R, int S, int stride, int pad, int H, int W) {
+    static const int on = getenv("DDL_CONV_ROWS") ? atoi(getenv("DDL_CONV_ROWS")) : 1;  // tuning knob
+    return on && C == 64 && N == 64 && R == 3 && S == 3 && stride == 1 && pad == 1 && W == 56 && H >= 2 && H % 2 == 0;
+}
+
+// y = conv3x3(x, w) for dense NHWC [B][H][56][64] tensors; `stats` ([B][2][64] fp32, may be null): per image
+// sum y | sum y^2 (forward) or, with `ep_y` / `ep_fcoef`, sum g | sum g*ep_y of the masked gradient g that is stored
+extern "C" int ddl_conv_rows3x3(const void* x, const void* w, void* y, void* stats, const void* ep_y, const void* ep_fcoef,
+                                int B, int H, int W, int C, int N, hipStream_t stream) {
+    if (!x || !w || !y || B <= 0) return DDL_EINVAL;
+    if (!ddl_conv_rows3x3_ok(C, N, 3, 3, 1, 1, H, W)) return DDL_EINVAL;
+    if ((ep_y == nullptr) != (ep_fcoef == nullptr) || (ep_y && !stats)) return DDL_EINVAL;
+    if (!ddl_aligned16(x) || !ddl_aligned16(w) || !ddl_aligned16(y) || (ep_y && !ddl_aligned16(ep_y)) ||
+        (ep_fcoef && !ddl_aligned16(ep_fcoef)) || (stats && !ddl_aligned16(stats))) return DDL_EALIGN;
+    const long long bytes = (long long)B * H * W * C * 2;
+    if (bytes >= 0x7fffffffLL) return DDL_EINVAL;
+    RowsParams p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.stats = (float*)stats;
+    p.ep_y = (const bf16_t*)ep_y; p.ep_fcoef = (const float*)ep_fcoef;
+    p.B = B; p.H = H; p.bytes = (unsigned)bytes;
+    if (ep_y) DDL_KLAUNCH((conv_rows3x3_kernel<true>), dim3(B), dim3(512), 0, stream, p);
+    else DDL_KLAUNCH((conv_rows3x3_kernel<false>), dim3(B), dim3(512), 0, stream, p);
+    return ddl_launch_status();
+}

@@ -925,6 +925,66 @@ __global__ void __launch_bounds__(256) bn_lin_prep_kernel(const bf16_t* __restri
     if (threadIdx.x == 0) bias[k] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The same preparation AND Q = a2 wt^T (bf16 [rows][rows], the second-segment weights) in ONE launch.  The two
+// launches it replaces (the kernel above, then a rows x rows GEMM over C on 1-4 workgroups of the conv
+// kernel: 12-39 us of a latency-bound loop) sat on the dependent chain in front of every block's first
+// backward-data kernel.  One workgroup per 16 x 16 tile of Q: its four waves split the C axis in steps of
+// 32 (one MFMA each, A = wt rows k scaled by cb and rounded to bf16 as a2 was, B = wt rows j) and meet in
+// LDS; the workgroups of the first tile column also write their 16 rows of b1 and bias.
+__global__ void __launch_bounds__(256) bn_lin_prep_q_kernel(const bf16_t* __restrict__ wt, int ld, const float* __restrict__ coef,
+                                                           int C, int rows, bf16_t* __restrict__ b1, bf16_t* __restrict__ q,
+                                                           float* __restrict__ bias) {
+    __shared__ float red[4][64][4];
+    __shared__ float bred[4][16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int r = lane & 15, g = lane >> 4;
+    const bool first = blockIdx.y == 0;
+    const bf16_t* wk = wt + (long long)(k0 + r) * ld;
+    const bf16_t* wj = wt + (long long)(j0 + r) * ld;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bacc = 0.f;
+    for (int c = wid * 32 + g * 8; c < C; c += 128) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(wk + c);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(wj + c);
+        float cb[8];
+        load8f(coef + C + c, cb);
+        bf16x8 a2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a2[e] = f2bf(bf2f(a[e]) * cb[e]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b, acc, 0, 0, 0);
+        if (first) {
+            float ca[8], cc[8];
+            load8f(coef + c, ca); load8f(coef + 2 * C + c, cc);
+            bf16x8 o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(a[e]);
+                o1[e] = f2bf(f * ca[e]);
+                bacc += f * cc[e];
+            }
+            *reinterpret_cast<bf16x8*>(b1 + (long long)(k0 + r) * C + c) = o1;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wid][lane][e] = acc[e];
+    if (first) {
+        bacc += __shfl_xor(bacc, 16, 64);
+        bacc += __shfl_xor(bacc, 32, 64);
+        if (lane < 16) bred[wid][lane] = bacc;
+    }
+    __syncthreads();
+    if (wid == 0) {
+        // D: lane holds rows 4g .. 4g+3 (k), column r (j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = (red[0][lane][e] + red[1][lane][e]) + (red[2][lane][e] + red[3][lane][e]);
+            q[(long long)(k0 + 4 * g + e) * rows + j0 + r] = f2bf(v);
+        }
+        if (first && lane < 16) bias[k0 + lane] = (bred[0][lane] + bred[1][lane]) + (bred[2][lane] + bred[3][lane]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Weight flip-transpose for backward-data, all tensors in one launch:
 //   dst[c][R-1-r][S-1-s][k] = src[k][r][s][c]   (k padded with zeros up to Kpad)
@@ -1374,6 +1434,15 @@ extern "C" int ddl_bn_lin_prep(const void* wt, int ld, const void* coef, int C, 
     CHK(ddl_aligned16(wt) && ddl_aligned16(coef) && ddl_aligned16(b1) && ddl_aligned16(a2), DDL_EALIGN);
     DDL_KLAUNCH(bn_lin_prep_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)wt, ld, (const float*)coef, C,
                        (bf16_t*)b1, (bf16_t*)a2, (float*)bias);
+    return ddl_launch_status();
+}
+
+extern "C" int ddl_bn_lin_prep_q(const void* wt, int ld, const void* coef, int C, int rows, void* b1, void* q, void* bias,
+                                 hipStream_t stream) {
+    CHK(wt && coef && b1 && q && bias && C > 0 && C <= 2048 && (C & 31) == 0 && rows > 0 && (rows & 15) == 0 && ld >= C && (ld & 7) == 0, DDL_EINVAL);
+    CHK(ddl_aligned16(wt) && ddl_aligned16(coef) && ddl_aligned16(b1) && ddl_aligned16(q), DDL_EALIGN);
+    DDL_KLAUNCH(bn_lin_prep_q_kernel, dim3(rows / 16, rows / 16), dim3(256), 0, stream, (const bf16_t*)wt, ld, (const float*)coef, C, rows,
+                       (bf16_t*)b1, (bf16_t*)q, (float*)bias);
     return ddl_launch_status();
 }
 

@@ -272,6 +272,16 @@ def _flush_notifications():
 
 
 # ---- raw (autograd-free) building blocks -------------------------------------------------------
+def _rows_ok(x, w, stride, padding):
+    """The row-streaming 3x3 kernel serves this conv (dense NHWC input, dense [K][3][3][C] filter)."""
+    if w.dim() != 4 or x.dim() != 4:
+        return False
+    B, C, H, W = x.shape
+    Kc, _, R, S = w.shape
+    return K.conv_rows3x3_ok(C, Kc, R, S, stride, padding, H, W) and \
+        x.stride() == (H * W * C, 1, W * C, C) and x.numel() * 2 < (1 << 31) - 1
+
+
 def _conv_fwd(x, w, stride, padding, want_stats):
     B, C, H, W = x.shape
     Kc, Cw, R, S = w.shape
@@ -281,6 +291,11 @@ def _conv_fwd(x, w, stride, padding, want_stats):
     Wo = (W + 2 * padding - S) // stride + 1
     y = _empty_nhwc(B, Kc, Ho, Wo, x.device)
     stats = None
+    if _rows_ok(x, w, stride, padding):
+        if want_stats:
+            stats = torch.empty((B, 2, Kc), dtype=torch.float32, device=x.device)
+        K.conv_rows3x3(x, w, y, stats=stats)
+        return y, stats
     if want_stats:
         stats = torch.empty((K.conv_tiles_m(B * Ho * Wo), 2, Kc), dtype=torch.float32,
                             device=x.device)
@@ -332,9 +347,14 @@ def _conv_dgrad_bn(dy, w, x_shape, stride, padding, y_prev, fcoef_prev):
     B, C, H, W = x_shape
     _, _, R, S = w.shape
     wt, wrows = _dgrad_w(w)
+    g = _empty_nhwc(B, C, H, W, dy.device)
+    if wrows == 0 and w.shape[0] == C and _rows_ok(dy, w, stride, padding) and \
+            y_prev.stride() == g.stride():
+        partial = torch.empty((B, 2, C), dtype=torch.float32, device=dy.device)   # one row per image
+        K.conv_rows3x3(dy, wt, g, stats=partial, ep_y=y_prev, ep_fcoef=fcoef_prev)
+        return g, partial
     T = K.conv_tiles_m_bwd(B * H * W, H, W, stride, 1)
     partial = torch.empty((T, 2, C), dtype=torch.float32, device=dy.device)
-    g = _empty_nhwc(B, C, H, W, dy.device)
     K.conv_igemm(dy, _geom(dy), wt, g, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
                  stats=partial, ep_y=y_prev, ep_fcoef=fcoef_prev, wt_rows=wrows)
     return g, partial
@@ -530,7 +550,8 @@ def _bn_fwd(y, gamma, beta, residual, stats, rmean, rvar, training, momentum, ep
             stats = torch.empty((T, 2, C), dtype=torch.float32, device=dev)
             K.bn_stats_partial(y, stats, M, C, rows)
         else:
-            rows, T = 128, stats.shape[0]
+            T = stats.shape[0]
+            rows = 128 if (T - 1) * 128 < M <= T * 128 else M // T   # (row-streaming conv: one row per image)
         K.bn_fwd_finalize(stats, T, C, M, rows, gamma, beta, rmean, rvar, momentum, eps,
                           coeffs[0], coeffs[1], coeffs[2], coeffs[3])
     else:
@@ -603,7 +624,8 @@ def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentu
     Ho = (H + 2 * padding - R) // stride + 1
     Wo = (W + 2 * padding - S) // stride + 1
     M = B * Ho * Wo
-    T = K.conv_tiles_m(M)
+    rows = _rows_ok(x, w, stride, padding)
+    T = B if rows else K.conv_tiles_m(M)      # (row-streaming kernel: one statistics row per image)
     P = K._fold_slices(T) if T > 512 else 0
     dev = x.device
     y = torch.empty((B, Kc, Ho, Wo), dtype=_BF16, device=dev, memory_format=_CL)
@@ -611,9 +633,12 @@ def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentu
     tmp = torch.empty(2 * T * Kc + 4 * P * Kc, dtype=torch.float32, device=dev)
     st = tmp.data_ptr()
     wk = st + 8 * T * Kc if P else None      # fp64 fold workspace (8-byte aligned: T*Kc*8 bytes in)
-    K.conv_igemm(x, _geom(x), w, y, Kc, R, S, stride, padding, padding, 1, Ho, Wo, stats=st)
+    if rows:
+        K.conv_rows3x3(x, w, y, stats=st)
+    else:
+        K.conv_igemm(x, _geom(x), w, y, Kc, R, S, stride, padding, padding, 1, Ho, Wo, stats=st)
     cb = coeffs.data_ptr()
-    K.bn_fwd_finalize(st, T, Kc, M, 128, gamma, beta, rmean, rvar, momentum, eps,
+    K.bn_fwd_finalize(st, T, Kc, M, Ho * Wo if rows else 128, gamma, beta, rmean, rvar, momentum, eps,
                       cb, cb + 4 * Kc, cb + 8 * Kc, cb + 12 * Kc, work=wk)
     if keep is not None:   # launched on another stream: the caller holds the scratch until the streams are ordered
         keep.append(tmp)
@@ -698,6 +723,15 @@ _DS_LINEAR = {"on": _os.environ.get("DDL_DS_LINEAR", "1") != "0",
               "max_cin": int(_os.environ.get("DDL_DS_LINEAR_MAX_CIN", "64"))}
 
 
+_LIN_PREP_Q = int(_os.environ.get("DDL_LIN_PREP_Q", "1"))
+# ... for these narrow widths.  Stage 3 (256) keeps the two launches: in the step the slow 4-workgroup GEMM is the
+# window in which the side stream's 256 x 256 weight-gradient workgroups (a whole CU each) get placed; without it
+# the step is 0.13 ms SLOWER although the chain is 0.1 ms shorter (profiles/r3_notes.md section 13)
+_LIN_PREP_Q_C2 = [int(v) for v in _os.environ.get("DDL_LIN_PREP_Q_C2", "64:128").split(":") if v]
+# the side stream starts a linear unit's raw weight-gradient product before the main stream folds / finalizes its coefficients
+_LIN_EARLY_SIDE = int(_os.environ.get("DDL_LIN_EARLY_SIDE", "0"))   # 2: its launches are issued first as well   # 0: the two-launch form (A/B switch)
+
+
 def _unit_coef(dz, y, gamma, beta, coeffs, partial):
     """Finalize pass only of a BatchNorm backward whose reduce partials already exist: returns the
     scratch tensor whose first 3*C floats are (ca, cb, cc); dgamma/dbeta go where _unit_bwd puts
@@ -755,12 +789,24 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
     C2 = z2.shape[1]
     dev = g.device
     wt3 = _WT.get(w)                      # [C2][C]: wt3[k][c] = w[c][k]
-    scratch = torch.empty(2 * C2 * C + C2 * C2, dtype=_BF16, device=dev)
-    b1, a2, q = scratch[:C2 * C], scratch[C2 * C: 2 * C2 * C], scratch[2 * C2 * C:]
     bias = torch.empty(C2, dtype=torch.float32, device=dev)
-    K.bn_lin_prep(wt3, C, coef_t.data_ptr(), C, C2, b1, a2, bias)
-    # Q[k][j] = sum_c cb[c] w[c][k] w[c][j]: a2 (rows k) times wt3^T, a C2 x C2 GEMM over C
-    K.conv_igemm(a2, (C2, 1, 1, C, C, C, C, a2.numel()), wt3, q, C2, 1, 1, 1, 0, 0, 1, 1, 1)
+    if _LIN_PREP_Q > 0 and (not _LIN_PREP_Q_C2 or C2 in _LIN_PREP_Q_C2):
+        # b1, bias and Q[k][j] = sum_c cb[c] w[c][k] w[c][j] in one launch (the dependent chain waits for it)
+        if _LIN_PREP_Q == 2:
+            scratch = torch.empty(2 * C2 * C + C2 * C2, dtype=_BF16, device=dev)
+            b1, q = scratch[:C2 * C], scratch[2 * C2 * C:]
+        else:
+            scratch = torch.empty(C2 * C + C2 * C2, dtype=_BF16, device=dev)
+            b1, q = scratch[:C2 * C], scratch[C2 * C:]
+        K.bn_lin_prep_q(wt3, C, coef_t.data_ptr(), C, C2, b1, q, bias)
+    else:
+        scratch = torch.empty(2 * C2 * C + C2 * C2, dtype=_BF16, device=dev)
+        b1, a2, q = scratch[:C2 * C], scratch[C2 * C: 2 * C2 * C], scratch[2 * C2 * C:]
+        K.bn_lin_prep(wt3, C, coef_t.data_ptr(), C, C2, b1, a2, bias)
+        # Q: a2 (rows k) times wt3^T, a C2 x C2 GEMM over C
+        K.conv_igemm(a2, (C2, 1, 1, C, C, C, C, a2.numel()), wt3, q, C2, 1, 1, 1, 0, 0, 1, 1, 1)
+        if _LIN_PREP_Q < 0:   # timing probe: the chain's price of this GEMM (issued twice)
+            K.conv_igemm(a2, (C2, 1, 1, C, C, C, C, a2.numel()), wt3, q, C2, 1, 1, 1, 0, 0, 1, 1, 1)
     g2 = _empty_nhwc(B, C2, H, W, dev)
     if y_prev is None:   # plain store (projection shortcut: the result is the addend of the block-input gradient)
         K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, x2=z2, w2=q, c2=C2, bias=bias)
@@ -836,12 +882,9 @@ def _bn3_linear_gram_forward(z2, w):
     return pre
 
 
-def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None):
-    """dW3 by linearity, into ``w.grad`` when that is a live arena view (returns None and notifies),
-    else returned.  Runs on the weight-gradient stream like _conv_wgrad: raw stream handle, one
-    persistent workspace carved by address (no torch stream switch, no allocations).  ``pre``: the
-    Gram part already computed during the forward pass (:func:`_bn3_linear_gram_forward`).
-    ``coeffs``: the BatchNorm's saved [4, C] block (its first row, the batch mean, is read here)."""
+def _bn3_linear_wgrad_start(g, z2, w, prewaited=False, pre=None):
+    """First half of :func:`_bn3_linear_wgrad`: everything that needs no BatchNorm coefficients (the raw
+    product g^T z2 and, unless ``pre`` has it, the Gram part).  Returns the state for the second half."""
     C, C2 = w.shape[0], w.shape[1]
     direct = _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]
     out = w.grad if direct else torch.zeros_like(w)
@@ -853,6 +896,7 @@ def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None):
     pbytes = (4 * splits * slab + 255) // 256 * 256
     tbytes = (2 * slab + 255) // 256 * 256
     total = pbytes + (0 if pre is not None else tbytes + 4 * 2 * C2 + 256 + _lin_gram_scratch_bytes(M, C, C2))
+    ws_t = None
     if side is None:
         ws_t = torch.empty(total, dtype=torch.uint8, device=g.device)
         base, raw = ws_t.data_ptr(), None
@@ -870,6 +914,15 @@ def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None):
         t = base + pbytes
         colz = t + tbytes
         _bn3_linear_gram(z2, w, raw, colz + 8 * C2, t, colz)   # (8*C2 bytes of column sums; C2 % 64 == 0 keeps the alignment)
+    return (g, z2, w, pre, direct, out, side, raw, partial, slab, splits, t, colz, C, C2, ws_t)
+
+
+def _bn3_linear_wgrad_finish(state, coef_t, coeffs, coef_late=False):
+    """Second half: the split-K reduction that applies the coefficients.  ``coef_late``: the side stream
+    was ordered behind the main one BEFORE the coefficients were computed there - wait again."""
+    g, z2, w, pre, direct, out, side, raw, partial, slab, splits, t, colz, C, C2, ws_t = state
+    if coef_late and raw is not None:
+        K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
     K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, colz, C2,
                         coeffs.data_ptr(), stream=raw)
     if side is not None:
@@ -886,6 +939,15 @@ def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None):
         _notify(w)
         return None
     return out
+
+
+def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None, coef_late=False):
+    """dW3 by linearity, into ``w.grad`` when that is a live arena view (returns None and notifies),
+    else returned.  Runs on the weight-gradient stream like _conv_wgrad: raw stream handle, one
+    persistent workspace carved by address (no torch stream switch, no allocations).  ``pre``: the
+    Gram part already computed during the forward pass (:func:`_bn3_linear_gram_forward`).
+    ``coeffs``: the BatchNorm's saved [4, C] block (its first row, the batch mean, is read here)."""
+    return _bn3_linear_wgrad_finish(_bn3_linear_wgrad_start(g, z2, w, prewaited, pre), coef_t, coeffs, coef_late)
 
 
 class _RawOut:
@@ -1320,15 +1382,20 @@ class ResidualBlockFn(Function):
             if last and i > 0 and mask == 0 and fused is not None and _FUSE_BN_REDUCE["on"] and \
                     _bn3_linear_ok(w, strides[i], pads[i], dz, inp):
                 # the wide unit by linearity: its dy never exists (see _bn3_linear_dgrad)
+                early = _LIN_EARLY_SIDE > 0 and _side_prewait(dz.device)   # the raw product g^T z2 needs no coefficients
+                wstate = None
+                if early and _LIN_EARLY_SIDE > 1:    # ... and is issued before the chain's kernels
+                    wstate = _bn3_linear_wgrad_start(dz, inp, w, prewaited=True, pre=getattr(ctx, "lin_pre", None))
                 coef_t, dg, db = _unit_coef(dz, ys[i], gam, bet, cs[i], fused)
                 g_short = dz
                 # the dependent chain first (the host is what the main stream waits for in the late
                 # layers: issuing the side-stream work first left 40-140 us holes in front of the prep kernel)
-                pre = _side_prewait(dz.device)   # the side stream may start before the chain's next kernels finish
+                pre = early or _side_prewait(dz.device)   # the side stream may start before the chain's next kernels finish
                 dz, fused = _bn3_linear_dgrad(g_short, inp, w, coef_t, ys[i - 1],
                                               cs[i - 1].data_ptr() + 8 * inp.shape[1])
-                dw = _bn3_linear_wgrad(g_short, inp, w, coef_t, cs[i], prewaited=pre,
-                                       pre=getattr(ctx, "lin_pre", None))
+                if wstate is None:
+                    wstate = _bn3_linear_wgrad_start(g_short, inp, w, prewaited=pre, pre=getattr(ctx, "lin_pre", None))
+                dw = _bn3_linear_wgrad_finish(wstate, coef_t, cs[i], coef_late=bool(early))
                 put(i, dw, dg, db)
                 _flush_notifications()
                 continue

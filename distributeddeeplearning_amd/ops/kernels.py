@@ -325,6 +325,36 @@ def conv_tiles_m(M):
 
 
 @functools.lru_cache(maxsize=None)
+def conv_rows3x3_ok(C, N, R, S, stride, pad, H, W):
+    """True when the row-streaming 3x3 kernel (csrc/kernels/conv_rows.hip) serves this layer, forward and
+    backward-data; its statistics / BatchNorm-backward partial table has ONE row per image."""
+    return bool(lib().ddl_conv_rows3x3_ok(_i32(C), _i32(N), _i32(R), _i32(S), _i32(stride), _i32(pad), _i32(H), _i32(W)))
+
+
+def conv_rows3x3(x, w, y, stats=None, ep_y=None, ep_fcoef=None, stream=None):
+    """y = conv3x3(x, w), stride 1, pad 1, for dense NHWC [B, 64, H, 56] tensors and a [64][3][3][64] filter.
+    ``stats`` ([B][2][64] fp32, tensor or raw address): per-image sum y | sum y^2; with ``ep_y`` + ``ep_fcoef``
+    (backward-data of a layer behind BatchNorm + ReLU) y is the masked gradient g and the table holds
+    sum g | sum g*ep_y."""
+    B, C, H, W = x.shape
+    N = y.shape[1]
+    if tuple(y.shape) != (B, N, H, W) or not conv_rows3x3_ok(C, N, 3, 3, 1, 1, H, W):
+        raise KernelError("conv_rows3x3: unsupported shape %s -> %s" % (tuple(x.shape), tuple(y.shape)))
+    for t in (x, y, ep_y):
+        if t is not None and (tuple(t.shape) != (B, C, H, W) or t.stride() != (H * W * C, 1, W * C, C)):
+            raise KernelError("conv_rows3x3: tensors must be dense channels_last [B, 64, H, 56]")
+    if w.numel() != N * 9 * C:
+        raise KernelError("conv_rows3x3: filter must hold [64][3][3][64] elements")
+    if stats is not None and stats.__class__ is not int and stats.numel() < B * 2 * N:
+        raise KernelError("conv_rows3x3: statistics table needs one row per image")
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG.append(("conv_rows", B, H, W, C, H, W, N, 3, 3, 1, 1, B * H * W, int(ep_y is not None)))
+    f = _fn("ddl_conv_rows3x3", "pppppp iiiii p")
+    check(f(x.data_ptr(), w.data_ptr(), y.data_ptr(), _p(stats), _p(ep_y), _p(ep_fcoef), B, H, W, C, N,
+            _raw_stream() if stream is None else stream), "conv_rows3x3")
+
+
+@functools.lru_cache(maxsize=None)
 def conv_tiles_m_bwd(M, Hout, Wout, idil, ostride):
     return int(lib().ddl_conv_igemm_tiles_m_bwd(_i64(M), _i32(Hout), _i32(Wout), _i32(idil),
                                                 _i32(ostride)))
@@ -384,6 +414,12 @@ def splitk_reduce_centered(partial, out, C, splits, colz, M, stream=None):
 def bn_lin_prep(wt, ld, coef, C, rows, b1, a2, bias):
     f = _fn("ddl_bn_lin_prep", "pi pii ppp p")
     check(f(_p(wt), ld, _p(coef), C, rows, _p(b1), _p(a2), _p(bias), _raw_stream()), "bn_lin_prep")
+
+
+def bn_lin_prep_q(wt, ld, coef, C, rows, b1, q, bias):
+    """:func:`bn_lin_prep` and Q = a2 wt^T (bf16 [rows][rows]) in one launch (a2 is never stored)."""
+    f = _fn("ddl_bn_lin_prep_q", "pi pii ppp p")
+    check(f(_p(wt), ld, _p(coef), C, rows, _p(b1), _p(q), _p(bias), _raw_stream()), "bn_lin_prep_q")
 
 
 def bn_colsum_fold(partial, T, C, out, stream=None):

@@ -1075,3 +1075,70 @@ def test_subsample2_is_the_strided_slice(shape):
     ref = x[:, :, ::2, ::2]
     assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("C,C2", [(256, 64), (512, 128), (1024, 256), (96, 64)])
+def test_bn_lin_prep_q_matches_the_two_launch_form(C, C2):
+    """One-launch weight preparation of the BatchNorm-by-linearity path (b1, bias, Q) against fp32 math
+    and against the two launches it replaces (scaling kernel + a GEMM of the conv kernel)."""
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    K.require()
+    g = torch.Generator(device=DEV).manual_seed(C + C2)
+    wt = (torch.randn((C2, C), generator=g, device=DEV) / math.sqrt(C2)).to(BF)
+    coef = torch.randn((3, C), generator=g, device=DEV)
+    b1 = torch.empty((C2, C), dtype=BF, device=DEV)
+    q = torch.empty((C2, C2), dtype=BF, device=DEV)
+    bias = torch.empty(C2, dtype=torch.float32, device=DEV)
+    K.bn_lin_prep_q(wt, C, coef.data_ptr(), C, C2, b1, q, bias)
+    w = wt.float()
+    assert torch.equal(b1, (w * coef[0]).to(BF))
+    assert torch.allclose(bias, (w * coef[2]).sum(1), rtol=1e-4, atol=1e-4)
+    a2 = (w * coef[1]).to(BF).float()
+    qr = a2 @ w.t()
+    assert relerr(q, qr) < 6e-3
+    if C % 64 == 0:   # the conv kernel's GEMM wants 64-channel multiples here
+        b1o, a2o, qo = torch.empty_like(b1), torch.empty_like(b1), torch.empty_like(q)
+        biaso = torch.empty_like(bias)
+        K.bn_lin_prep(wt, C, coef.data_ptr(), C, C2, b1o, a2o, biaso)
+        K.conv_igemm(a2o, (C2, 1, 1, C, C, C, C, a2o.numel()), wt, qo, C2, 1, 1, 1, 0, 0, 1, 1, 1)
+        assert torch.equal(b1, b1o)
+        assert torch.allclose(bias, biaso, rtol=1e-5, atol=1e-5)
+        assert relerr(q, qo) < 6e-3
+
+
+@pytest.mark.parametrize("B,H", [(3, 56), (2, 6)])
+def test_conv_rows3x3_forward_and_masked_backward(B, H):
+    """Row-streaming 3x3 kernel (64 -> 64 channels, 56-pixel rows): forward with per-image statistics, and the
+    backward-data form that masks with relu(bn(y_prev)) and keeps the BatchNorm-backward sums, against fp32."""
+    from distributeddeeplearning_amd.ops import hip_ops as hip, kernels as K
+
+    K.require()
+    if not K.conv_rows3x3_ok(64, 64, 3, 3, 1, 1, H, 56):
+        pytest.skip("row-streaming kernel switched off")
+    x = rand_nhwc(B, 64, H, 56, seed=11)
+    w = (torch.randn((64, 64, 3, 3), device=DEV) / 24.0).to(BF).contiguous(memory_format=CL)
+    y = torch.empty_like(x)
+    stats = torch.full((B, 2, 64), float("nan"), device=DEV)
+    K.conv_rows3x3(x, w, y, stats=stats)
+    yr = F.conv2d(x.float(), w.float(), None, 1, 1)
+    assert relerr(y, yr) < 1.5e-2 and rms_relerr(y, yr) < 4e-3
+    yf = y.float()
+    assert torch.allclose(stats[:, 0], yf.sum((2, 3)), rtol=1e-3, atol=1e-2 * float(yf.abs().max()))
+    assert torch.allclose(stats[:, 1], (yf * yf).sum((2, 3)), rtol=1e-3, atol=1e-3)
+    # backward-data: dy -> masked gradient of relu(bn(y_prev)); the filter operand is the flipped transpose
+    dy = rand_nhwc(B, 64, H, 56, seed=12)
+    y_prev = rand_nhwc(B, 64, H, 56, seed=13)
+    fco = torch.stack([torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.3]).contiguous()
+    g, part = hip._conv_dgrad_bn(dy, w, x.shape, 1, 1, y_prev, fco.data_ptr())
+    assert part.shape == (B, 2, 64)
+    dxr = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), 1, 1)
+    on = (y_prev.float() * fco[0].view(1, -1, 1, 1) + fco[1].view(1, -1, 1, 1)) > 0
+    # (elements within rounding distance of the ReLU threshold may flip: compare where the decision is clear)
+    clear = (y_prev.float() * fco[0].view(1, -1, 1, 1) + fco[1].view(1, -1, 1, 1)).abs() > 1e-3
+    gr = dxr * on
+    assert relerr(g.float() * clear, gr * clear) < 1.5e-2
+    gf = g.float()
+    assert torch.allclose(part[:, 0], gf.sum((2, 3)), rtol=1e-3, atol=1e-2 * float(gf.abs().max()))
+    assert torch.allclose(part[:, 1], (gf * y_prev.float()).sum((2, 3)), rtol=1e-3, atol=1e-2 * float(gf.abs().max()))
+    hip.reset_caches()
