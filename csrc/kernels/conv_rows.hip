@@ -6,16 +6,18 @@
 // does 16 MFMAs per wave and meets at a barrier; three workgroups per CU take turns waiting for DMA
 // (114 us forward for 59 GFLOP and 206 MB; profiles/r3_conv_roofline_v2.txt).  Here
 //   * a workgroup (8 waves) owns ONE IMAGE and walks down its rows, two output rows per step;
-//   * the filter never touches LDS: wave (nh, mg) keeps the [32 output channels][9 taps][64 channels] slice of
-//     its half nh in 144 registers for the whole image (MFMA A operand, D rows = output channels);
+//   * the filter passes through LDS once per workgroup (72 KB by DMA, next to the first rows) and then lives in
+//     registers: wave (nh, mg) keeps the [32 output channels][9 taps][64 channels] slice of its half nh in 144
+//     registers for the whole image (MFMA A operand, D rows = output channels);
 //   * input rows go global -> LDS exactly once, by LDS-DMA, into a ring of row slots (64 pixels x 128 bytes: pixel
 //     0 and pixels 57.. are the zero halo, written by the DMA's range check; rows above / below the image
-//     likewise), DEPTH steps ahead, waited for with counted `vmcnt` and one barrier per step;
+//     likewise), two steps ahead, waited for with counted `vmcnt` and one barrier per step;
 //   * tap (r, s) of output pixel (row, w) is slot row + r, pixel w + s: the MFMA B operand is one 16-byte LDS
 //     read per lane (16 pixels x 32 channels per fragment), each fragment feeds the two output rows that see its
 //     input row and both 16-channel tiles: 72 MFMAs per 24 LDS reads per wave and step;
 //   * D columns are pixels and D rows channels, so a lane holds 4 consecutive channels of one pixel: the epilogue
-//     stores 8 bytes per lane straight from the accumulators - no LDS staging of the output tile.
+//     stores 8 bytes per lane straight from the (rounded) accumulators - no LDS staging of the output tile - and
+//     the epilogue of step t-1 sits between the multiplies of step t.
 // Every vector-memory instruction of the loop (DMA, output stores) is inline asm: hipcc's wait-count insertion
 // never sees one and never drains the ring with `vmcnt(0)`; stores only make the counted waits stricter
 // (loads return in order among themselves, stores do not return in order with loads).
@@ -40,7 +42,8 @@ struct RowsParams {
 
 __device__ __forceinline__ void gstore8(u32x4 rsrc, unsigned voff, unsigned soff, u32x2 v) {
     soff = __builtin_amdgcn_readfirstlane(soff);
-    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    // (no "memory" clobber: the kernel never reads its output back, and LDS reads may move across the store)
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(rsrc), "s"(soff));
 }
 
 template <int N>
@@ -48,12 +51,26 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 template <bool BWD>
 __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
-    constexpr int W = 56, C = 64, DEPTH = 3;
-    constexpr int NSX = 2 * DEPTH + 2, NSY = DEPTH + 1;          // x row slots; y groups (two rows each)
+    constexpr int W = 56, C = 64;
+    constexpr int NSX = 8, NSY = 4;                               // x row slots; y groups (two rows each)
     constexpr int SLOT = 8192, XBYTES = NSX * SLOT + 256;         // + 256: the last tile's tap reads run 2 pixels past its slot
-    constexpr int YBASE = XBYTES, YBYTES = BWD ? NSY * 2 * SLOT : 0;
-    constexpr int FBASE = YBASE + YBYTES, FBYTES = BWD ? 512 : 0;
+    constexpr int WBYTES = 64 * 9 * C * 2;                        // the whole filter, staged once
+    constexpr int YBASE = XBYTES;                                 // y ring (BWD) - the filter's staging area before the loop
+    constexpr int FBASE = YBASE + WBYTES, FBYTES = BWD ? 512 : 0;
+    static_assert(NSY * 2 * SLOT <= WBYTES, "the y ring lives in the filter's staging area");
     constexpr int NPW = BWD ? 4 : 2;                              // DMA instructions per wave and step
+#ifndef DDL_CROWS_ISSUE_AT
+#define DDL_CROWS_ISSUE_AT 2
+#endif
+#ifndef DDL_CROWS_PRIO
+#define DDL_CROWS_PRIO 0
+#endif
+    // Wave priority experiments (profiles/r3_notes.md section 13): 1 = a wave runs the first half of its step at
+    // raised priority (of the two waves of a SIMD the one that is BEHIND wins; by age waves 0-3 finish 800 cycles
+    // early and wait at the barrier), 2 = waves 4-7 always high.  Cycles per step 3386 / 3338 / 3373 forward,
+    // 3901 / 4184 / 3884 backward-data for 0 / 1 / 2: the SIMD's total is what counts, not who wins.
+    constexpr int PRIO = DDL_CROWS_PRIO;
+    constexpr int ISSUE_AT = DDL_CROWS_ISSUE_AT;                  // input row of the step behind whose reads the DMA is issued
     constexpr unsigned INVALID = 0x80000000u;
     __shared__ __attribute__((aligned(16))) unsigned char smem[FBASE + FBYTES];
 
@@ -61,22 +78,13 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
     const int nh = wid >> 2, mg = wid & 3;
     const int col = lane & 15, g = lane >> 4;
     const int b = blockIdx.x, H = p.H, T = H >> 1;
+#ifdef DDL_CROWS_PROBE
+    const unsigned long long cstart = __builtin_readcyclecounter();
+#endif
 
     const u32x4 xr = raw_rsrc(p.x, p.bytes), yr = raw_rsrc(p.y, p.bytes);
-    const u32x4 er = raw_rsrc(BWD ? p.ep_y : p.x, p.bytes);
+    const u32x4 er = raw_rsrc(BWD ? p.ep_y : p.x, p.bytes), wr = raw_rsrc(p.w, WBYTES);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-
-    // ---- the filter slice of this wave: [tap][channel half][16-channel tile] fragments, A operand
-    //      (lane: row = output channel col of the tile, 8 reduction channels 32h + 8g ..)
-    bf16x8 wreg[9][2][2];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                wreg[tap][h][j] = *reinterpret_cast<const bf16x8*>(p.w + ((32 * nh + 16 * j + col) * 9 + tap) * C + 32 * h + 8 * g);
-    if (BWD && tid < 128) reinterpret_cast<float*>(smem + FBASE)[tid] = p.ep_fcoef[tid];
 
     // ---- DMA geometry.  A wave moves pieces q0, q0+1 (8 pixels each) of row (wid >> 2) of the step's two rows.
     //      x: LDS pixel j = image column j - 1; 16-byte chunk c of pixel j sits at chunk c ^ ((j >> 1) & 7)
@@ -90,23 +98,32 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
         xv[i] = (xcol >= 0 && xcol < W) ? (unsigned)(xcol * 128 + ch * 16) : INVALID;
         yv_off[i] = (q0 + i) < 7 ? (unsigned)((q0 + i) * 1024 + lane * 16) : INVALID;     // 56 pixels = 7 pieces, linear
     }
-    // group k: x rows v = 2k+2, 2k+3 (v = image row + 1; v = 0 and v = H+1 are zero rows) and, BWD, the y rows of step k
-    auto issue = [&](int k) {
+    // x rows v = 2k+2, 2k+3 (v = image row + 1; v = 0 and v = H+1 are zero rows)
+    auto issue_x = [&](int k) {
         const int v = 2 * k + 2 + r2;
         const bool ok = v >= 1 && v <= H;                                   // uniform
         const unsigned soff = ok ? (unsigned)((b * H + v - 1) * W) * 128u : 0u;
-        const unsigned dst = lds0 + (unsigned)(((v + NSX * 4) % NSX) * SLOT + q0 * 1024);
+        const unsigned dst = lds0 + (unsigned)(((v + NSX) % NSX) * SLOT + q0 * 1024);
         lds_dma16(xr, dst, ok ? xv[0] : INVALID, soff);
         lds_dma16(xr, dst + 1024, ok ? xv[1] : INVALID, soff);
-        if (BWD) {
-            const int row = 2 * k + r2;
-            const bool yok = row >= 0 && row < H;
-            const unsigned ysoff = yok ? (unsigned)((b * H + row) * W) * 128u : 0u;
-            const unsigned yd = lds0 + (unsigned)(YBASE + ((k + NSY * 4) % NSY) * 2 * SLOT + r2 * SLOT + q0 * 1024);
-            lds_dma16(er, yd, yok ? yv_off[0] : INVALID, ysoff);
-            lds_dma16(er, yd + 1024, yok ? yv_off[1] : INVALID, ysoff);
-        }
     };
+    // BWD: the y_prev rows of step k (output rows 2k, 2k+1)
+    auto issue_y = [&](int k) {
+        const int row = 2 * k + r2;
+        const bool yok = row >= 0 && row < H;
+        const unsigned ysoff = yok ? (unsigned)((b * H + row) * W) * 128u : 0u;
+        const unsigned yd = lds0 + (unsigned)(YBASE + ((k + NSY) % NSY) * 2 * SLOT + r2 * SLOT + q0 * 1024);
+        lds_dma16(er, yd, yok ? yv_off[0] : INVALID, ysoff);
+        lds_dma16(er, yd + 1024, yok ? yv_off[1] : INVALID, ysoff);
+    };
+
+    // ---- prologue: the filter (72 pieces of 1 KiB, 9 per wave) and the first six x rows are fetched together
+#pragma unroll
+    for (int i = 0; i < 9; ++i) lds_dma16(wr, lds0 + (unsigned)(YBASE + (wid + 8 * i) * 1024), (unsigned)((wid + 8 * i) * 1024 + lane * 16), 0u);
+    issue_x(-1);
+    issue_x(0);
+    issue_x(1);
+    if (BWD && tid < 128) reinterpret_cast<float*>(smem + FBASE)[tid] = p.ep_fcoef[tid];
 
     // ---- fragment read offsets inside a row slot: [s][channel half]
     int xo[3][2];
@@ -123,48 +140,104 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) ov[j] = pvalid ? (unsigned)((px * C + 32 * nh + 16 * j + 4 * g) * 2) : INVALID;
 
-    // the filter registers are complete BEFORE the loop: hipcc would otherwise wait for them (`vmcnt(0)`) at their
-    // first use inside it, on every iteration, and empty the DMA ring
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- the filter slice of this wave: [tap][channel half][16-channel tile] fragments, A operand
+    //      (lane: row = output channel col of the tile, 8 reduction channels 32h + 8g ..), kept for the whole image
+    bf16x8 wreg[9][2][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                wreg[tap][h][j] = *reinterpret_cast<const bf16x8*>(smem + YBASE + (((32 * nh + 16 * j + col) * 9 + tap) * C + 32 * h + 8 * g) * 2);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)   // (complete before the staging area is reused)
         asm volatile("" : "+v"(wreg[tap][0][0]), "+v"(wreg[tap][0][1]), "+v"(wreg[tap][1][0]), "+v"(wreg[tap][1][1]));
+    if (BWD) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_y(0);
+        issue_y(1);
+    }
 
+    if (PRIO == 2 && nh == 1) __builtin_amdgcn_s_setprio(1);
     f32x4 acc[2][2];
+    bf16x4 res[2][2];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j) {
+            acc[o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            res[o][j] = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+        }
     float s1[2][4], s2[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[j][e] = 0.f; s2[j][e] = 0.f; }
 
-    // ---- prologue: rows v = 0, 1 (half a group), then groups 0 .. DEPTH-1
-    {
-        const int v = r2;
-        const bool ok = v >= 1;
-        const unsigned soff = ok ? (unsigned)((b * H + v - 1) * W) * 128u : 0u;
-        const unsigned dst = lds0 + (unsigned)(v * SLOT + q0 * 1024);
-        lds_dma16(xr, dst, ok ? xv[0] : INVALID, soff);
-        lds_dma16(xr, dst + 1024, ok ? xv[1] : INVALID, soff);
-    }
+    // epilogue of output row 2*te + o (results in `res`): mask (BWD), statistics, 8-byte stores.  `live` = te >= 0.
+    auto epilogue = [&](int te, int o, bool live) {
+        const unsigned soff = live ? (unsigned)((b * H + 2 * te + o) * W) * 128u : 0u;
+        const bool pv = pvalid && live;
 #pragma unroll
-    for (int k = 0; k < DEPTH; ++k) issue(k);
-    wait_vm<(DEPTH - 1) * NPW>();           // rows 0..3 (and the y rows of step 0) have landed
-    __builtin_amdgcn_s_barrier();
+        for (int j = 0; j < 2; ++j) {
+            bf16x4 v = res[o][j];
+            if (BWD) {
+                const int ch0 = 32 * nh + 16 * j + 4 * g;
+                const bf16x4 yv = *reinterpret_cast<const bf16x4*>(smem + YBASE + ((te + NSY) % NSY) * 2 * SLOT + o * SLOT + px * 128 + ch0 * 2);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + FBASE + ch0 * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(smem + FBASE + 256 + ch0 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // (`res` is zero for pad pixels and before the first step, and the y ring is finite there:
+                    // zero DMA fill, or the staged filter - no selects on the sums)
+                    const float yf = bf2f(yv[e]);
+                    const bool on = bn_affine(yf, sc[e], sh[e]) > 0.f;
+                    v[e] = on ? v[e] : f2bf(0.f);
+                    const float gg = bf2f(v[e]);
+                    s1[j][e] += gg; s2[j][e] += gg * yf;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float f = bf2f(v[e]);
+                    s1[j][e] += f; s2[j][e] += f * f;
+                }
+            }
+            gstore8(yr, pv ? ov[j] : INVALID, soff, __builtin_bit_cast(u32x2, v));
+        }
+    };
 
+#ifdef DDL_CROWS_PROBE
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, c0, c1;
+#define CROWS_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); c1 = __builtin_readcyclecounter(); ph[i] += c1 - c0; c0 = c1; __builtin_amdgcn_sched_barrier(0); } while (0)
+    c0 = __builtin_readcyclecounter();
+    ph[5] = c0 - cstart;                       // prologue: filter registers, first rows
+#else
+#define CROWS_STAMP(i) do { } while (0)
+#endif
+    // Step t: the multiplies of step t with, in between, the epilogue of step t-1 and the DMA of group t+2 (its
+    // slots were last read in step t-1, before the barrier) - the matrix pipe works through the stores, the
+    // statistics arithmetic and the DMA issue - then the counted wait for group t+1 and the barrier.
     for (int t = 0; t < T; ++t) {
-        // ---- multiply: input row i of the step (v = 2t + i) feeds output row o with tap row r = i - o
         const int v0 = 2 * t;
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (PRIO == 1 && i == 2) __builtin_amdgcn_s_setprio(0);
             const unsigned char* row = smem + ((v0 + i) % NSX) * SLOT;
             bf16x8 f[3][2];
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) f[s][h] = *reinterpret_cast<const bf16x8*>(row + xo[s][h]);
+            if (i == ISSUE_AT) {   // (behind this row's fragment reads: the DMA's "memory" clobber pins LDS reads)
+                issue_x(t + 2);
+                if (BWD) issue_y(t + 2);
+            }
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
                 const int r = i - o;
@@ -177,48 +250,39 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
                         for (int j = 0; j < 2; ++j)
                             acc[o][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[r * 3 + s][h][j], f[s][h], acc[o][j], 0, 0, 0);
             }
+            if (i == 0) epilogue(t - 1, 0, t > 0);
+            if (i == 1) epilogue(t - 1, 1, t > 0);
         }
-        // ---- group t+1 has landed (everywhere, after the barrier) and everybody is done with rows 2t, 2t+1
-        wait_vm<(DEPTH - 2) * NPW>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue(t + DEPTH);
-
-        // ---- epilogue of step t: 4 channels of one pixel per lane and tile
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const unsigned soff = (unsigned)((b * H + 2 * t + o) * W) * 128u;
+        for (int o = 0; o < 2; ++o)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bf16x4 v;
-                if (BWD) {
-                    const int ch0 = 32 * nh + 16 * j + 4 * g;
-                    const bf16x4 yv = *reinterpret_cast<const bf16x4*>(smem + YBASE + (t % NSY) * 2 * SLOT + o * SLOT + px * 128 + ch0 * 2);
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + FBASE + ch0 * 4);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(smem + FBASE + 256 + ch0 * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float yf = bf2f(yv[e]);
-                        const bool on = bn_affine(yf, sc[e], sh[e]) > 0.f;
-                        v[e] = on ? f2bf(acc[o][j][e]) : f2bf(0.f);
-                        const float gg = pvalid ? bf2f(v[e]) : 0.f;
-                        s1[j][e] += gg; s2[j][e] += gg * yf;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = f2bf(acc[o][j][e]);
-                        const float f = pvalid ? bf2f(v[e]) : 0.f;
-                        s1[j][e] += f; s2[j][e] += f * f;
-                    }
-                }
-                gstore8(yr, ov[j], soff, __builtin_bit_cast(u32x2, v));
+                for (int e = 0; e < 4; ++e) res[o][j][e] = pvalid ? f2bf(acc[o][j][e]) : f2bf(0.f);   // pad pixels (56..63) hold garbage
                 acc[o][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        }
+        CROWS_STAMP(0);
+        // ---- group t+1 has landed (everywhere, after the barrier) and everybody is done with rows 2t, 2t+1
+        wait_vm<NPW>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        CROWS_STAMP(1);
+        __builtin_amdgcn_s_barrier();
+        CROWS_STAMP(2);
     }
+    epilogue(T - 1, 0, true);
+    epilogue(T - 1, 1, true);
     wait_vm<0>();
     if (p.stats == nullptr) return;
+#ifdef DDL_CROWS_PROBE
+    // timing build: the table receives cycles per phase (multiply + epilogue, DMA wait, barrier, DMA issue) of
+    // every wave instead of statistics
+    __syncthreads();
+    if (lane == 0) {
+        ph[6] = __builtin_readcyclecounter() - cstart;   // whole kernel
+        for (int i = 0; i < 7; ++i) p.stats[(long long)b * 128 + wid * 8 + i] = (float)ph[i];
+    }
+    return;
+#endif
 
     // ---- statistics of the image: fold the 16 pixel lanes, then the four pixel groups (fixed order)
 #pragma unroll
