@@ -60,6 +60,11 @@ def _cost(rec):
         by += 2.0 * M * N * (addend + ep_y + ep_y2) + (M * N / 8.0) * ep_mask
         tag = ("dgrad" if bwd else "fwd") + ("+st" if stats and not ep_y else "") + ("+bnbwd" if ep_y else "") + \
               ("+mask" if ep_mask else "") + ("+add" if addend else "") + ("+y2" if ep_y2 else "") + ("+seg2" if c2 else "")
+    elif kind == "conv_rows":
+        bwd = rec[13]
+        flops = 2.0 * M * N * R * S * C
+        by = 2.0 * (M * C + M * N + N * R * S * C) + 2.0 * M * N * bwd
+        tag = "rows " + ("dgrad+bnbwd" if bwd else "fwd+st")
     else:
         splits = rec[13]
         Kred = M
@@ -77,8 +82,9 @@ def join(trace_csv, log_json):
     step = rows[last:]
     log = json.load(open(log_json))
     out = []
-    for kind in ("conv_igemm", "conv_wgrad"):
-        ks = [r for r in step if kind + "_kernel" in r["Kernel_Name"] or (kind == "conv_wgrad" and "conv_wgrad256_kernel" in r["Kernel_Name"])]
+    for kind in ("conv_igemm", "conv_wgrad", "conv_rows"):
+        ks = [r for r in step if kind + "_kernel" in r["Kernel_Name"] or (kind == "conv_wgrad" and ("conv_wgrad256_kernel" in r["Kernel_Name"] or "conv_wgrad_rows_kernel" in r["Kernel_Name"]))
+              or (kind == "conv_rows" and "conv_rows3x3_kernel" in r["Kernel_Name"])]
         ls = [r for r in log if r[0] == kind]
         if len(ks) != len(ls):
             print("# %s: %d kernels in the trace, %d launches logged - not joined" % (kind, len(ks), len(ls)))
