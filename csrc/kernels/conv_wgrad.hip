@@ -35,6 +35,10 @@ struct WgradParams {
     // take its 32/64-row tiles round-robin, so the whole grid sweeps every group front to back - the
     // order in which the backward-data kernel running next to it reads the same two tensors
     int il_sg, il_mg;
+    // COLSUM kernels (plain GEMMs): [splits][2][C] column sums of x over each split's rows, both rows alike (the
+    // layout of a statistics table: bn_colsum_fold sums it) - the matrix pipe adds them up on the side (a row of
+    // ones as a 17th "output channel" fragment), so the Gram launch of the linear path needs no extra pass over x
+    float* colsum;
 };
 
 __device__ __forceinline__ u32x4 wg_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -53,8 +57,8 @@ __device__ __forceinline__ int lds_swz(int row) {
     return ROW_BYTES == 256 ? (row & 7) : ((row >> 1) & 3);
 }
 
-template <int BMw, int BNw, bool SIMPLE, bool UNITAP, bool GLDS, int BK = 32>
-__global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p) {
+template <int BMw, int BNw, bool SIMPLE, bool UNITAP, bool GLDS, int BK = 32, bool COLSUM = false>
+__global__ void __launch_bounds__(256, COLSUM ? 3 : 4) conv_wgrad_kernel(const WgradParams p) {
     static_assert(!GLDS || ((BMw == 64 || BMw == 128) && (BNw == 64 || BNw == 128)), "LDS-DMA image: 128- or 256-byte rows");
     static_assert(BK == 32 || (BK == 64 && GLDS), "64 reduction rows per tile only with LDS-DMA staging (no staging registers)");
     constexpr int A_STR = BMw * 2 + (GLDS ? 0 : 32), B_STR = BNw * 2 + (GLDS ? 0 : 32);  // row strides (bytes)
@@ -226,6 +230,14 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cacc[COLSUM ? FN : 1];
+    bf16x8 ones;
+    if (COLSUM) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) cacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = f2bf(1.f);
+    }
 
     // transposing-read addressing: lane 16g + 4q + pq supplies row (4g + q [+16]), cols 4pq..4pq+3
     const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
@@ -266,6 +278,10 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (COLSUM && wm == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) cacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[j], cacc[j], 0, 0, 0);
+        }
         }
         if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (kt + 1 < KT) stash(cur ^ 1);
@@ -286,6 +302,16 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
                 if (n < p.K && jc < RSC) out[(long long)n * RSC + jc] = acc[i][j][e];
             }
         }
+    if (COLSUM && wm == 0 && tile_k == 0 && fq == 0) {   // every D row holds the column sums: lanes 0..15 have row 0
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int jc = j0 + wn * WN + j * 16 + fr;
+            if (jc < RSC) {
+                p.colsum[((long long)split * 2) * RSC + jc] = cacc[j][0];
+                p.colsum[((long long)split * 2 + 1) * RSC + jc] = cacc[j][0];
+            }
+        }
+    }
 }
 
 // ---- 256 x 256 tile, 8 waves, LDS-DMA ring with tiles in flight across the barrier ----------------
@@ -304,8 +330,9 @@ __global__ void __launch_bounds__(256, 4) conv_wgrad_kernel(const WgradParams p)
 // Rows are 512 bytes: window w (32 bytes) of row r sits at window w ^ (r & 7) as in the kernel above,
 // applied on the SOURCE address of the DMA (the LDS image of one wave-instruction is linear) and on
 // the read address.
-template <bool SIMPLE, int NST, bool PIPE>
+template <bool SIMPLE, int NST, bool PIPE, bool COLSUM = false>
 __global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p) {
+    static_assert(!COLSUM || !PIPE, "column sums ride in the plain loop");
     constexpr int BK = 32, ROWB = 512, HALF = BK * ROWB, STAGE = 2 * HALF, CPR = 32, LOADS = 2;
     constexpr int FM = 8, FN = 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
@@ -422,6 +449,15 @@ __global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    f32x4 cacc[COLSUM ? FN : 1];
+    bf16x8 ones;
+    if (COLSUM) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) cacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = f2bf(1.f);
+    }
+
     const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
     const int tr_row = 4 * g + q, swz = tr_row & 7;
     // byte offsets of this lane's fragment reads inside a stage (row tr_row; the second half of a fragment is 16 rows down)
@@ -512,6 +548,10 @@ __global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (COLSUM && wm == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) cacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bfr[j], cacc[j], 0, 0, 0);
+        }
         // tile kt+1 has landed (this wave's part; the barrier makes it everyone's); every LDS read of this
         // tile has retired, so the next iteration may overwrite the stage
         wait_tiles(NST - 2);
@@ -536,6 +576,16 @@ __global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p)
                 if (n < p.K && jc < RSC) out[(long long)n * RSC + jc] = acc[i][j][e];
             }
         }
+    if (COLSUM && wm == 0 && tile_k == 0 && fq == 0) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int jc = j0 + wn * 64 + j * 16 + fr;
+            if (jc < RSC) {
+                p.colsum[((long long)split * 2) * RSC + jc] = cacc[j][0];
+                p.colsum[((long long)split * 2 + 1) * RSC + jc] = cacc[j][0];
+            }
+        }
+    }
 }
 
 // ---- 3x3 / stride 1 / pad 1 layers with 64 or 128 channels: row-streaming kernel ------------------
@@ -873,6 +923,13 @@ int launch_wgrad(WgradParams& p, hipStream_t stream) {
             return ddl_launch_status();
         }
     }
+    if (p.colsum) {   // (the caller checked: plain GEMM, register-staged, a tile shape that has the instantiation)
+        if constexpr ((BMw == 64 && BNw == 64) || (BMw == 128 && BNw == 128)) {
+            DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, true, true, false, 32, true>), grid, block, 0, stream, p);
+            return ddl_launch_status();
+        }
+        return DDL_EINVAL;
+    }
     if (p.simple) DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, true, true, false>), grid, block, 0, stream, p);
     else if (p.C % BNw == 0) DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, false, true, false>), grid, block, 0, stream, p);
     else DDL_KLAUNCH((conv_wgrad_kernel<BMw, BNw, false, false, false>), grid, block, 0, stream, p);
@@ -970,10 +1027,24 @@ extern "C" int ddl_conv_wgrad_splits(long long M, int K, int C, int R, int S) {
     return (int)want;
 }
 
-extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
-                              int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
-                              int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
-                              hipStream_t stream) {
+// plain-GEMM weight gradients that can emit the column sums of x on the side
+extern "C" int ddl_conv_wgrad_colsum_ok(long long M, int K, int C) {
+    static const int on = getenv("DDL_WGRAD_COLSUM") ? atoi(getenv("DDL_WGRAD_COLSUM")) : 1;  // tuning knob
+    if (!on) return 0;
+    if (wgrad_big(M, K, C, 1, 1)) return 1;
+    static const int glds_env = getenv("DDL_WGRAD_GLDS") ? atoi(getenv("DDL_WGRAD_GLDS")) : -1;
+    if (glds_env > 0) return 0;            // (the LDS-DMA forms have no such instantiation)
+    int bm, bn;
+    wgrad_tile(K, C, 1, 1, bm, bn);
+    return (bm == 64 && bn == 64) || (bm == 128 && bn == 128);
+}
+
+// `colsum` (optional; plain GEMMs whose tile shape has the instantiation - ddl_conv_wgrad_colsum_ok): [splits][2][C]
+// fp32 column sums of x per split (a statistics-table layout, both rows alike)
+extern "C" int ddl_conv_wgrad_ex(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
+                                 int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                 int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
+                                 void* colsum, hipStream_t stream) {
     if (!dy || !x || !partial || B <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || splits <= 0) return DDL_EINVAL;
     if (C % 8 != 0 || K % 8 != 0) return DDL_EINVAL;
     if (dy_numel <= 0 || x_numel <= 0) return DDL_EINVAL;
@@ -997,11 +1068,13 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
     mps = (mps + 31) / 32 * 32;
     p.m_per_split = (int)mps;
     p.il_sg = p.il_mg = 0;
+    p.colsum = (float*)colsum;
     // 32-bit offsets inside one split: its dy rows, and the images its x rows come from
     if ((mps + 64) * K * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     if ((mps / ((long long)Hout * Wout) + 3) * xs_b * 2 >= 0x7fffffffLL || (mps + 64) * xs_w * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     p.simple = (R == 1 && S == 1 && stride == 1 && pad == 0 && pad_w == 0 && Hin == Hout && Win == Wout &&
                 xs_h == (long long)Win * xs_w && xs_b == (long long)Hin * xs_h) ? 1 : 0;
+    if (colsum && !(p.simple && ddl_conv_wgrad_colsum_ok(M, K, C))) return DDL_EINVAL;
     if (wgrad_rows(K, C, R, S, Hout, Wout, stride, B) && pad == 1 && pad_w == 1 && Hin == Hout && Win == Wout &&
         xs_w == C && xs_h == (long long)Win * C && xs_b == (long long)Hin * Win * C &&
         p.dy_bytes < 0x7fffffffLL && p.x_bytes < 0x7fffffffLL) {
@@ -1021,6 +1094,10 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
         dim3 grid(p.tiles_k * p.tiles_rsc * p.splits), block(512);
         static const int pipe = getenv("DDL_WGRAD_BIG_PIPE") ? atoi(getenv("DDL_WGRAD_BIG_PIPE")) : 0;  // tuning knob
 #define BIGL(SIMP, N, P) DDL_KLAUNCH((conv_wgrad256_kernel<SIMP, N, P>), grid, block, 0, stream, p)
+        if (colsum) {
+            DDL_KLAUNCH((conv_wgrad256_kernel<true, 3, false, true>), grid, block, 0, stream, p);
+            return ddl_launch_status();
+        }
         if (pipe) {
             if (nst == 4) { if (p.simple) BIGL(true, 4, true); else BIGL(false, 4, true); }
             else { if (p.simple) BIGL(true, 3, true); else BIGL(false, 3, true); }
@@ -1053,6 +1130,14 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long
     }
     if (bn == 64) return launch_wgrad<128, 64>(p, stream);
     return launch_wgrad<128, 128>(p, stream);
+}
+
+extern "C" int ddl_conv_wgrad(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
+                              int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                              int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
+                              hipStream_t stream) {
+    return ddl_conv_wgrad_ex(dy, x, partial, dy_numel, x_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout, K, R, S,
+                             stride, pad, pad_w, splits, nullptr, stream);
 }
 
 extern "C" int ddl_splitk_reduce(const void* partial, void* out, long long n, int splits, long long slab,

@@ -1099,6 +1099,13 @@ extern "C" int ddl_bn_stats_partial(const void* y, void* partial, long long M, i
     return ddl_launch_status();
 }
 
+// Partial tables of at most this many rows are summed by the finalize kernel itself (one launch); longer ones are
+// folded by many CUs first (two launches).  DDL_BN_DIRECT_MAX overrides (sweep in profiles/r3_notes.md).
+extern "C" int ddl_bn_direct_max() {
+    static const int v = getenv("DDL_BN_DIRECT_MAX") ? atoi(getenv("DDL_BN_DIRECT_MAX")) : 512;  // tuning knob
+    return v < 1 ? 1 : v;
+}
+
 // workspace (doubles) needed by ddl_bn_fwd_finalize for T tiles of C channels
 extern "C" long long ddl_bn_fold_slices(int T) {
     // ~64 tiles per slice, at most 32 slices — 128 for the longest tables (the stem's 25088 tiles
@@ -1114,10 +1121,10 @@ extern "C" int ddl_bn_fwd_finalize(const void* partial, int T, int C, long long 
                                    const void* beta, void* rmean, void* rvar, float momentum, float eps, void* mean,
                                    void* invstd, void* scale, void* shift, void* workspace, hipStream_t stream) {
     CHK(partial && gamma && beta && mean && invstd && scale && shift && T > 0 && C > 0 && M > 0, DDL_EINVAL);
-    CHK(workspace || T <= 512, DDL_EINVAL);
+    CHK(workspace || T <= ddl_bn_direct_max(), DDL_EINVAL);
     CHK((long long)T * rows_per_tile >= M && (long long)(T - 1) * rows_per_tile < M, DDL_EINVAL);
     CHK((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, DDL_EALIGN);
-    if (T <= 512) {
+    if (T <= ddl_bn_direct_max()) {
         DDL_KLAUNCH(bn_fwd_finalize_direct_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, (const float*)partial, T, C,
                            M, (const float*)gamma, (const float*)beta, (float*)rmean, (float*)rvar, momentum, eps,
                            (float*)mean, (float*)invstd, (float*)scale, (float*)shift);
@@ -1212,7 +1219,7 @@ extern "C" int ddl_bn_bwd_finalize(const void* partial, int G, int C, long long 
                                    const void* invstd, void* dgamma, void* dbeta, void* coef, int accumulate,
                                    void* workspace, hipStream_t stream) {
     CHK(partial && gamma && mean && invstd && dgamma && dbeta && coef && G > 0 && C > 0 && M > 0, DDL_EINVAL);
-    if (workspace && G > 512) {
+    if (workspace && G > ddl_bn_direct_max()) {
         const int P = (int)ddl_bn_fold_slices(G);
         static const int one = getenv("DDL_BN_ONE_LAUNCH") ? atoi(getenv("DDL_BN_ONE_LAUNCH")) : 0;   // A/B knob: measured slower, profiles/r2_notes.md
         int* tickets = one && C <= 4096 ? bn_tickets() : nullptr;

@@ -626,7 +626,7 @@ def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentu
     M = B * Ho * Wo
     rows = _rows_ok(x, w, stride, padding)
     T = B if rows else K.conv_tiles_m(M)      # (row-streaming kernel: one statistics row per image)
-    P = K._fold_slices(T) if T > 512 else 0
+    P = K._fold_slices(T) if T > K.bn_direct_max() else 0
     dev = x.device
     y = torch.empty((B, Kc, Ho, Wo), dtype=_BF16, device=dev, memory_format=_CL)
     coeffs = torch.empty((4, Kc), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
@@ -669,7 +669,7 @@ def _unit_bwd(dz, y, z, gamma, beta, coeffs, mask, want_g, partial=None):
     else:
         G = partial.shape[0]
         own = 0
-    P = K._fold_slices(G) if G > 512 else 0
+    P = K._fold_slices(G) if G > K.bn_direct_max() else 0
     tmp = torch.empty(3 * C + own + 2 * P * C, dtype=torch.float32, device=dev)
     coef = tmp.data_ptr()
     if partial is None:
@@ -741,7 +741,7 @@ def _unit_coef(dz, y, gamma, beta, coeffs, partial):
     dev = y.device
     cb = coeffs.data_ptr()
     G = partial.shape[0]
-    P = K._fold_slices(G) if G > 512 else 0
+    P = K._fold_slices(G) if G > K.bn_direct_max() else 0
     tmp = torch.empty(3 * C + 2 * P * C, dtype=torch.float32, device=dev)
     coef = tmp.data_ptr()
     wk = coef + 12 * C if P else None
@@ -838,9 +838,14 @@ def _bn3_linear_gram(z2, w, raw, base, t, colz):
     gp = base
     gram = gp + (4 * s2 * gslab + 255) // 256 * 256
     zp = gram + (2 * gslab + 255) // 256 * 256
-    K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2, stream=raw)
-    K.bn_stats_partial(z2, zp, M, C2, rows, stream=raw)
-    K.bn_colsum_fold(zp, Tz, C2, colz, stream=raw)
+    if K.conv_wgrad_colsum_ok(M, C2, C2):
+        # the Gram launch sums the columns of z2 on the side (a row of ones through the matrix pipe): no extra pass over z2
+        K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2, stream=raw, colsum=zp)
+        K.bn_colsum_fold(zp, s2, C2, colz, stream=raw)
+    else:
+        K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2, stream=raw)
+        K.bn_stats_partial(z2, zp, M, C2, rows, stream=raw)
+        K.bn_colsum_fold(zp, Tz, C2, colz, stream=raw)
     K.splitk_reduce_centered(gp, gram, C2, s2, colz, M, stream=raw)   # z2^T z2 - colz (x) colz / M
     # T = W3 (centred Gram): rows c of the filter times the (symmetric) matrix
     K.conv_igemm(w, (C, 1, 1, C2, C2, C2, C2, w.numel()), gram, _RawOut(t, C * C2), C2, 1, 1, 1, 0, 0, 1, 1, 1,
@@ -850,7 +855,7 @@ def _bn3_linear_gram(z2, w, raw, base, t, colz):
 def _lin_gram_scratch_bytes(M, C, C2):
     rows, Tz, s2 = _lin_gram_layout(M, C, C2)
     gslab = C2 * C2
-    return (4 * s2 * gslab + 255) // 256 * 256 + (2 * gslab + 255) // 256 * 256 + 4 * Tz * 2 * C2 + 256
+    return (4 * s2 * gslab + 255) // 256 * 256 + (2 * gslab + 255) // 256 * 256 + 4 * max(Tz, s2) * 2 * C2 + 256
 
 
 # The forward pass leaves the weight-gradient stream idle: the Gram part of a block that will take
@@ -1078,7 +1083,7 @@ class StemFn(Function):
         geom = (B, H, W + 1, 32, H * (W + 8) * 4, (W + 8) * 4, 4, xp.numel())
         M = B * Ho * Wo
         T = K.conv_tiles_m(M)
-        P = K._fold_slices(T) if T > 512 else 0
+        P = K._fold_slices(T) if T > K.bn_direct_max() else 0
         y = _empty_nhwc(B, Kc, Ho, Wo, dev)
         coeffs = torch.empty((4, Kc), dtype=torch.float32, device=dev)
         tmp = torch.empty(2 * T * Kc + 4 * P * Kc, dtype=torch.float32, device=dev)
@@ -1107,7 +1112,7 @@ class StemFn(Function):
         M = B * Ho * Wo
         dev = y.device
         G = min(max(M // 64, 1), _STEM_REDUCE_BLOCKS)
-        P = K._fold_slices(G) if G > 512 else 0
+        P = K._fold_slices(G) if G > K.bn_direct_max() else 0
         tmp = torch.empty(3 * Kc + 2 * G * Kc + 2 * P * Kc, dtype=torch.float32, device=dev)
         coef = tmp.data_ptr()
         part = coef + 12 * Kc

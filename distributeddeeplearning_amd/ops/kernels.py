@@ -369,17 +369,25 @@ def conv_wgrad_splits(M, K, C, R, S, Hout=0, Wout=0, stride=1, B=0):
                                               _i32(stride), _i32(B)))
 
 
+@functools.lru_cache(maxsize=None)
+def conv_wgrad_colsum_ok(M, K, C):
+    """True when the plain-GEMM weight gradient of this shape can emit the column sums of its x operand."""
+    return bool(lib().ddl_conv_wgrad_colsum_ok(_i64(M), _i32(K), _i32(C)))
+
+
 def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hout, Wout, splits,
-               stream=None):
-    """``partial``: tensor or raw address; ``stream``: raw HIP stream (default: current)."""
+               stream=None, colsum=None):
+    """``partial``: tensor or raw address; ``stream``: raw HIP stream (default: current).  ``colsum`` (raw address
+    or tensor, plain GEMMs with :func:`conv_wgrad_colsum_ok`): receives [splits][2][C] fp32 column sums of x per
+    split, both rows alike - a statistics-table layout that :func:`bn_colsum_fold` sums."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
     if _PROBE_SKIP_WGRAD == "all" or (_PROBE_SKIP_WGRAD == "late" and Hout <= 14) or (_PROBE_SKIP_WGRAD == "early" and Hout > 14):
         return   # timing probe only (gradients are garbage): what the step costs without these launches
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append(("conv_wgrad", B, Hin, Win, C, Hout, Wout, K, R, S, stride, 1, dy.numel() // K, splits))
-    f = _fn("ddl_conv_wgrad", "ppp qq iiii qqq iiiiiiiii p")
+    f = _fn("ddl_conv_wgrad_ex", "ppp qq iiii qqq iiiiiiiii p p")
     check(f(dy.data_ptr(), x_ptr_tensor.data_ptr(), _p(partial), dy.numel(), xn, B, Hin, Win,
-            C, sb, sh, sw, Hout, Wout, K, R, S, stride, pad, pad_w, splits,
+            C, sb, sh, sw, Hout, Wout, K, R, S, stride, pad, pad_w, splits, _p(colsum),
             _raw_stream() if stream is None else stream), "conv_wgrad")
 
 
@@ -441,11 +449,17 @@ def _fold_slices(T):
     return int(lib().ddl_bn_fold_slices(_i32(T)))
 
 
+@functools.lru_cache(maxsize=None)
+def bn_direct_max():
+    """Longest statistics / BatchNorm-backward partial table the finalize kernels sum in one launch."""
+    return int(lib().ddl_bn_direct_max())
+
+
 def bn_fwd_finalize(partial, T, C, M, rows_per_tile, gamma, beta, rmean, rvar, momentum, eps,
                     mean, invstd, scale, shift, work=None):
     """``work``: [fold_slices(T), 2, C] float64 scratch, needed (and allocated here unless given)
     only for tables of more than 512 tiles."""
-    if work is None and T > 512:
+    if work is None and T > bn_direct_max():
         work = torch.empty((_fold_slices(T), 2, C), dtype=torch.float64, device=partial.device)
     f = _fn("ddl_bn_fwd_finalize", "p iiqi pppp ff ppppp p")
     check(f(_p(partial), T, C, M, rows_per_tile, gamma.data_ptr(), beta.data_ptr(), _p(rmean),
@@ -484,7 +498,7 @@ def bn_bwd_reduce(dz, y, z, fcoef, partial, M, C, mask, G):
 def bn_bwd_finalize(partial, G, C, M, gamma, mean, invstd, dgamma, dbeta, coef, accumulate=False,
                     work=None):
     """``work``: [fold_slices(G), 2, C] float32 scratch for tables of more than 512 rows."""
-    if work is None and G > 512:
+    if work is None and G > bn_direct_max():
         work = torch.empty((_fold_slices(G), 2, C), dtype=torch.float32, device=gamma.device)
     f = _fn("ddl_bn_bwd_finalize", "p iiq pppppp i pp")
     check(f(_p(partial), G, C, M, gamma.data_ptr(), _p(mean), _p(invstd), _p(dgamma), _p(dbeta),

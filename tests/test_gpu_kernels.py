@@ -1142,3 +1142,24 @@ def test_conv_rows3x3_forward_and_masked_backward(B, H):
     assert torch.allclose(part[:, 0], gf.sum((2, 3)), rtol=1e-3, atol=1e-2 * float(gf.abs().max()))
     assert torch.allclose(part[:, 1], (gf * y_prev.float()).sum((2, 3)), rtol=1e-3, atol=1e-2 * float(gf.abs().max()))
     hip.reset_caches()
+
+
+@pytest.mark.parametrize("B,C2,hw", [(6, 64, 56), (5, 128, 28), (24, 256, 14)])
+def test_gram_weight_gradient_emits_column_sums(B, C2, hw):
+    """The Gram launch of the BatchNorm-by-linearity path (z2^T z2 as a plain-GEMM weight gradient) sums the columns
+    of z2 on the side: slabs and column sums against fp32."""
+    from distributeddeeplearning_amd.ops import hip_ops as hip, kernels as K
+
+    K.require()
+    M = B * hw * hw
+    if not K.conv_wgrad_colsum_ok(M, C2, C2):
+        pytest.skip("column sums switched off or no instantiation for this tile")
+    z2 = (rand_nhwc(B, C2, hw, hw, seed=21).float().relu() + 0.25).to(BF).contiguous(memory_format=CL)
+    s2 = K.conv_wgrad_splits(M, C2, C2, 1, 1)
+    slabs = torch.empty((s2, C2, C2), dtype=torch.float32, device=DEV)
+    cs = torch.full((s2, 2, C2), float("nan"), device=DEV)
+    K.conv_wgrad(z2, z2, hip._geom(z2), slabs, C2, 1, 1, 1, 0, 0, hw, hw, s2, colsum=cs)
+    zf = z2.float().permute(0, 2, 3, 1).reshape(M, C2)
+    assert torch.allclose(cs[:, 0].sum(0), zf.sum(0), rtol=1e-4)
+    assert torch.equal(cs[:, 0], cs[:, 1])
+    assert relerr(slabs.sum(0), zf.t() @ zf) < 1e-3
