@@ -247,7 +247,7 @@ def _i32(v):
     return ctypes.c_int(int(v))
 
 
-# timing probe (scripts/gpu_r3_probe.sh): DDL_PROBE_SKIP_WGRAD=all|late|early drops the weight-gradient GEMMs, =reduce the plain slab reductions
+# timing probe (run through scripts/gpu_sweep.sh): DDL_PROBE_SKIP_WGRAD=all|late|early drops the weight-gradient GEMMs, =reduce the plain slab reductions
 _PROBE_SKIP_WGRAD = os.environ.get("DDL_PROBE_SKIP_WGRAD", "")
 
 # diagnostic: a list that receives one tuple per conv launch (scripts/conv_roofline.py); None = off

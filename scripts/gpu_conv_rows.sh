@@ -1,7 +1,7 @@
 #!/bin/bash
 # row-streaming conv kernel: tests, phase cycles (probe library) and kernel durations from a kernel trace
 set -o pipefail
-OUT=gpurun_out/${TAG:-r3crows2}
+OUT=gpurun_out/${TAG:-conv_rows}
 mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
 timeout -k 10 300 python -u -m pytest tests/test_gpu_kernels.py -x -q -k "conv_rows3x3 or conv_fwd_bwd" --timeout 120 --timeout-method thread 2>&1 | tail -3 || exit 1

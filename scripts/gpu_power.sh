@@ -1,7 +1,7 @@
 #!/bin/bash
 # clocks and power while the flagship runs (is the step power-limited?)
 set -o pipefail
-OUT=gpurun_out/${TAG:-r3power}
+OUT=gpurun_out/${TAG:-power}
 mkdir -p $OUT
 rocm-smi --showclocks --showpower --showtemp > $OUT/idle.txt 2>&1
 timeout -k 10 200 python -u bench.py --steps 1500 --warmup 6 > $OUT/bench.log 2>&1 &

@@ -1,7 +1,7 @@
 #!/bin/bash
-# in-step sweep of the big weight-gradient kernel's knobs (alternating with the baseline)
+# in-step sweep: SWEEP="VAR=V,VAR2=W VAR=X ..." runs the flagship once per space-separated entry (commas join several variables)
 set -o pipefail
-OUT=gpurun_out/${TAG:-r3wg2}
+OUT=gpurun_out/${TAG:-sweep}
 mkdir -p $OUT
 run() {
   env "$@" timeout -k 10 200 python -u bench.py --steps 30 --warmup 6 > $OUT/bench.log 2>&1 || { tail -20 $OUT/bench.log; exit 1; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tape tests, then the flagship eagerly / from the tape, then the kernel statistics of the taped run
 set -o pipefail
-OUT=gpurun_out/${TAG:-r3a}
+OUT=gpurun_out/${TAG:-tape}
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 600 python -u -m pytest tests/test_gpu_tape.py tests/test_gpu_kernels.py -k "tape or subsample" -m gpu -v --timeout 240 --timeout-method thread > $OUT/tape.log 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel trace of the taped flagship under an environment given in ENVS (space separated VAR=VAL), output tag TAG
 set -o pipefail
-OUT=gpurun_out/${TAG:-r3trace}
+OUT=gpurun_out/${TAG:-trace}
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # row-streaming 3x3 weight-gradient kernel: numerics, isolated, in-step (DDL_WGRAD_ROWS=0 is the tile kernel)
 set -o pipefail
-OUT=gpurun_out/${TAG:-r3rows}
+OUT=gpurun_out/${TAG:-wgrad_rows}
 mkdir -p $OUT
 timeout -k 10 500 python -u -m pytest tests/test_gpu_numerics.py tests/test_gpu_kernels.py -k "conv or block or chain or linearity or wgrad or resnet50_trains" -m gpu -x -q --timeout 200 --timeout-method thread > $OUT/num.log 2>&1
 tail -3 $OUT/num.log | cut -c1-300
