@@ -107,6 +107,9 @@ def main(argv=None):
     else:
         opt = FusedSGD(model.named_parameters(), lr=lr, momentum=0.9)
     opt = hvd.DistributedOptimizer(opt, named_parameters=model.named_parameters())
+    # one process: each gradient bucket is updated as soon as it is complete, next to the rest of backward
+    # (nothing here touches gradients between backward() and step()); DDL_EARLY_UPDATE=0 = all updates in step()
+    early_update = os.environ.get("DDL_EARLY_UPDATE", "1") != "0" and opt.enable_early_update()
 
     loader = DeviceSyntheticLoader(args.batch, length=args.batch * world * (args.steps + args.warmup),
                                    height=args.image, width=args.image, device=device,
@@ -232,6 +235,7 @@ def main(argv=None):
             "hip_graph": bool(graphed is not None and graphed.graphed),
             # launch tape: the timed steps were replayed from native code (launches per step) or issued from Python
             "launch_tape": bool(taped is not None and taped.taped),
+            "early_update": bool(early_update),
             "tape_launches": taped.launches if (taped is not None and taped.taped) else None,
             "tape_refused": None if (taped is None or taped.failed is None) else str(taped.failed)[:200],
             "reserved_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1) if use_cuda else 0.0,

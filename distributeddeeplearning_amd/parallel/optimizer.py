@@ -125,7 +125,7 @@ class _CommMetrics:
 
 class _BucketState:
     __slots__ = ("dtype", "bucket", "tensor", "pending", "expected", "work", "launched",
-                 "needs_scale", "wire", "ctx")
+                 "needs_scale", "wire", "ctx", "early_done")
 
     def __init__(self, dtype, bucket, tensor, passes=1):
         self.dtype = dtype
@@ -138,6 +138,7 @@ class _BucketState:
         self.needs_scale = False
         self.wire = None
         self.ctx = None
+        self.early_done = False      # updated during backward (DistributedOptimizer.enable_early_update)
 
 
 class _DistributedMixin:
@@ -165,6 +166,8 @@ class _DistributedMixin:
         self._ddl_order_seen = []
         self._ddl_order_checked = False
         self._ddl_direct_seen = set()
+        self._ddl_early = False          # enable_early_update
+        self._ddl_in_direct = False
         self._ddl_fault = _parse_fault(cfg.fault_inject)
         self._ddl_corrupt = _parse_fault(cfg.fault_corrupt)
         # replica check: after each of the first N steps (every step in debug mode) all ranks compare
@@ -234,7 +237,48 @@ class _DistributedMixin:
         served here; counting both launched every bucket after HALF of its gradients."""
         if id(p) in self._ddl_names:
             self._ddl_direct_seen.add(id(p))
-            self._ddl_arrive(p)
+            self._ddl_in_direct = True
+            try:
+                self._ddl_arrive(p)
+            finally:
+                self._ddl_in_direct = False
+
+    # -- one process: update a bucket as soon as its gradients are complete ----------------------------
+    def enable_early_update(self, on=True):
+        """ONE process (no communicator), fused HIP path, one backward pass per step, and nothing between
+        ``backward()`` and ``step()`` that reads or rewrites gradients (clipping!): a bucket whose
+        gradients are complete is updated right away, on the weight-gradient stream next to the rest of
+        backward, instead of in ``step()`` behind it - the reference's update waits for the whole backward
+        pass (``HorovodPytorch/src/imagenet_pytorch_horovod.py:216-218``).  Same kernels, same arguments,
+        same values: backward reads the transposed weight copies (refreshed after ``step()``), the
+        forward filters of a complete bucket have no reader left, and the stream is ordered behind the
+        main stream's gradient writes.  Returns whether the mode is active."""
+        base = super(self.__class__, self)
+        ok = bool(on) and _b.size() == 1 and _b.comm() is None and self._ddl_passes == 1 and \
+            getattr(base, "step_bucket", None) is not None and _b.engine_config().per_bucket_update
+        if ok:
+            try:
+                from ..ops import kernels as _kernels
+
+                ok = self._ddl_arena.device.type == "cuda" and _kernels.enabled()
+            except Exception:  # pragma: no cover - ops layer unavailable
+                ok = False
+        self._ddl_early = ok
+        return ok
+
+    def _ddl_early_update(self, st):
+        from ..ops import hip_ops as _hip_ops, kernels as _kernels
+
+        base = super(self.__class__, self)
+        raw = _hip_ops._side_stream(st.tensor.device).cuda_stream
+        # behind the main stream's gradient writes queued so far (BatchNorm finalize kernels, the stem);
+        # the weight gradients themselves were reduced on this very stream
+        _kernels.stream_wait_stream(raw, _kernels._raw_stream(), _hip_ops._SIDE["event"])
+        base.begin_step()
+        with _kernels.launch_on(raw):
+            base.step_bucket(st.dtype, st.bucket.start, st.bucket.end)
+        _hip_ops._side_mark_used()      # the end-of-backward join orders the main stream behind the update
+        st.early_done = True
 
     def _ddl_on_grad(self, p):
         if id(p) in self._ddl_direct_seen:
@@ -244,6 +288,8 @@ class _DistributedMixin:
     def _ddl_launch(self, st):
         st.launched = True
         if _b.size() == 1 and _b.comm() is None:
+            if self._ddl_early and self._ddl_in_direct and not self._ddl_checking():
+                self._ddl_early_update(st)
             return
         # the hand-off to the communication engine cannot live on a launch tape: it runs as a live
         # action, again and in place at every replay of a recorded step (ops/tape.py)
@@ -442,6 +488,9 @@ class _DistributedMixin:
         per_bucket = getattr(base, "step_bucket", None)
         checking = self._ddl_checking()
         if per_bucket is None or closure is not None or not _b.engine_config().per_bucket_update or checking:
+            if any(st.early_done for st in self._ddl_buckets):
+                raise RuntimeError("early bucket updates already ran in this step: the whole-arena step would apply "
+                                   "them twice (closure / replica check with enable_early_update)")
             self.synchronize()
             self._ddl_reset_buckets()
             self._ddl_maybe_corrupt()
@@ -459,6 +508,9 @@ class _DistributedMixin:
         for st in self._ddl_buckets:
             with _trace.range("wait+update %s.bucket%d" % (str(st.dtype).replace("torch.", ""), st.bucket.index)):
                 self._ddl_finish(st)
+                if st.early_done:       # updated during backward (enable_early_update)
+                    st.early_done = False
+                    continue
                 per_bucket(st.dtype, st.bucket.start, st.bucket.end)
         if self._ddl_metrics is not None:
             _tape.live(self._ddl_metrics.end_step)

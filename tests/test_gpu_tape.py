@@ -199,3 +199,44 @@ hvd.shutdown()
     assert t["segments"] > t["buckets"] and t["actions"] >= 2 * t["buckets"]
     assert t["losses"] == e["losses"] and t["sum"] == e["sum"]
     assert t["metrics"]["comm_exposed_ms"] is not None
+
+
+def test_early_bucket_updates_are_bit_identical_to_the_plain_step():
+    """One process: `DistributedOptimizer.enable_early_update()` updates every bucket as soon as its gradients
+    are complete (on the weight-gradient stream, during backward).  Same parameters, momenta and losses, bit for
+    bit, as updating everything in step() - eagerly and from the launch tape."""
+    import distributeddeeplearning_amd.torch as hvd
+    from distributeddeeplearning_amd.models import build_model
+    from distributeddeeplearning_amd.ops import functional as ops
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    dev = torch.device("cuda", 0)
+
+    def run(early, steps=4):
+        torch.manual_seed(7)
+        model = build_model("resnet50", num_classes=1000).to_compute(dev, torch.bfloat16).train()
+        base = FusedSGD(model.named_parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        opt = hvd.DistributedOptimizer(base, named_parameters=model.named_parameters())
+        assert opt.enable_early_update(early) == early
+        g = torch.Generator(device=dev).manual_seed(3)
+        x = torch.randn((16, 3, 224, 224), generator=g, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y = torch.randint(0, 1000, (16,), generator=g, device=dev)
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = ops.softmax_cross_entropy(model(x), y)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        arena = opt.arena
+        return losses, {str(dt): arena.params[dt].clone() for dt in arena.params}, \
+            {str(dt): opt.momentum_buf[dt].clone() for dt in opt.momentum_buf}
+
+    l0, p0, m0 = run(False)
+    l1, p1, m1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    for k in m0:
+        assert torch.equal(m0[k], m1[k]), k
