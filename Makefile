@@ -8,6 +8,8 @@ Usage:
     make smoke       2-rank local smoke run of the training script on synthetic data
     make build       build the training docker image       (image=..., see deploy/build.mk)
     make push        push the training docker image
+    make flavours    build the per-script training images on top of it (trainer = Keras-flavoured script,
+                     estimator = TF-Estimator-flavoured script; the base image runs the PyTorch-flavoured one)
     make control     build the control-plane image (docker CLI + Jupyter :9999)
     make jupyter     run Jupyter inside the control image
 endef
@@ -46,6 +48,10 @@ smoke: native
 
 include deploy/build.mk
 
+flavours: build
+	docker build -t $(image)-trainer --build-arg BASE_IMAGE=$(image) -f deploy/docker/trainer.Dockerfile .
+	docker build -t $(image)-estimator --build-arg BASE_IMAGE=$(image) -f deploy/docker/estimator.Dockerfile .
+
 control:
 	docker build -t $(control_image) -f deploy/docker/control.Dockerfile .
 
@@ -54,4 +60,4 @@ jupyter:
 	    -v $(PWD):/workspace -v $(data):/data -v /var/run/docker.sock:/var/run/docker.sock \
 	    -it $(control_image) bash -c "jupyter notebook"
 
-.PHONY: help native test gpu-test bench smoke control jupyter
+.PHONY: help native test gpu-test bench smoke flavours control jupyter
