@@ -181,3 +181,26 @@ def test_trace_gaps_reports_streams_and_gaps(tmp_path):
                          capture_output=True, text=True, check=True).stdout
     assert "queue 1 stream 0: 3 kernels" in out and "queue 2 stream 1: 1 kernels" in out
     assert "50.0 us" in out and "conv_igemm_kernel<a> -> bn_apply" in out
+
+
+def test_flavour_images_point_at_real_scripts_and_known_settings():
+    """The per-flavour Dockerfiles (reference: one image per framework flavour) only carry entry points and
+    defaults: every script they start exists and every setting they export is one the scripts read."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg_src = open(os.path.join(root, "distributeddeeplearning_amd", "utils", "config.py")).read()
+    for name in ("trainer.Dockerfile", "estimator.Dockerfile"):
+        text = open(os.path.join(root, "deploy", "docker", name)).read()
+        scripts = re.findall(r"examples/[a-z_]+\.py", text)
+        assert scripts, name
+        for s in scripts:
+            assert os.path.exists(os.path.join(root, s)), (name, s)
+        env_block = re.search(r"^ENV (.*?)(?=^\S)", text, re.S | re.M).group(1)
+        keys = re.findall(r"([A-Z_]+)=", env_block)
+        assert "DISTRIBUTED" in keys
+        for k in keys:
+            if k == "DDL_FLAVOUR":
+                continue
+            assert '"%s"' % k in cfg_src, (name, k)
+        assert "ddlrun" in text and "BASE_IMAGE" in text
