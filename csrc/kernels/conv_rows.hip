@@ -16,8 +16,9 @@
 //     read per lane (16 pixels x 32 channels per fragment), each fragment feeds the two output rows that see its
 //     input row and both 16-channel tiles: 72 MFMAs per 24 LDS reads per wave and step;
 //   * D columns are pixels and D rows channels, so a lane holds 4 consecutive channels of one pixel: the epilogue
-//     stores 8 bytes per lane straight from the (rounded) accumulators - no LDS staging of the output tile - and
-//     the epilogue of step t-1 sits between the multiplies of step t.
+//     stores 16 bytes per lane (its two tiles' rows are dealt so that they are 8 consecutive channels) straight from
+//     the (rounded) accumulators - no LDS staging of the output tile - and the epilogue of step t-1 sits between the
+//     multiplies of step t.
 // Every vector-memory instruction of the loop (DMA, output stores) is inline asm: hipcc's wait-count insertion
 // never sees one and never drains the ring with `vmcnt(0)`; stores only make the counted waits stricter
 // (loads return in order among themselves, stores do not return in order with loads).
@@ -40,10 +41,14 @@ struct RowsParams {
     unsigned bytes;         // of one activation tensor
 };
 
-__device__ __forceinline__ void gstore8(u32x4 rsrc, unsigned voff, unsigned soff, u32x2 v) {
+__device__ __forceinline__ void gstore16(u32x4 rsrc, unsigned voff, unsigned soff, u32x4 v) {
     soff = __builtin_amdgcn_readfirstlane(soff);
     // (no "memory" clobber: the kernel never reads its output back, and LDS reads may move across the store)
-    asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" :: "v"(v), "v"(voff), "s"(rsrc), "s"(soff));
+    // The wait states behind the store are part of the asm: a VMEM store of more than 8 bytes must not be followed at
+    // once by a VALU write of its data registers (gfx9 store-data hazard).  hipcc pads its OWN stores but does not
+    // look inside inline asm - without the s_nop the stored rows were occasionally wrong, and only in the training
+    // step (the partner wave's issue timing decides what comes next), never in the isolated kernel.
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rsrc), "s"(soff));
 }
 
 template <int N>
@@ -136,9 +141,10 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
     // ---- epilogue geometry: this lane's pixel and its 4 channels per 16-channel tile
     const int px = 16 * mg + col;
     const bool pvalid = px < W;
-    unsigned ov[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) ov[j] = pvalid ? (unsigned)((px * C + 32 * nh + 16 * j + 4 * g) * 2) : INVALID;
+    // Output channels are dealt to the two 16-row MFMA tiles of a wave so that a lane's 4 + 4 rows are 8 CONSECUTIVE
+    // channels (tile j, row q  <->  channel 32*nh + 8*(q / 4) + 4*j + q % 4): one 16-byte store / LDS read per pixel
+    const int ch8 = 32 * nh + 8 * g;
+    const unsigned ov = pvalid ? (unsigned)((px * C + ch8) * 2) : INVALID;
 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -151,7 +157,7 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                wreg[tap][h][j] = *reinterpret_cast<const bf16x8*>(smem + YBASE + (((32 * nh + 16 * j + col) * 9 + tap) * C + 32 * h + 8 * g) * 2);
+                wreg[tap][h][j] = *reinterpret_cast<const bf16x8*>(smem + YBASE + (((32 * nh + 8 * (col >> 2) + 4 * j + (col & 3)) * 9 + tap) * C + 32 * h + 8 * g) * 2);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)   // (complete before the staging area is reused)
         asm volatile("" : "+v"(wreg[tap][0][0]), "+v"(wreg[tap][0][1]), "+v"(wreg[tap][1][0]), "+v"(wreg[tap][1][1]));
@@ -178,37 +184,33 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[j][e] = 0.f; s2[j][e] = 0.f; }
 
-    // epilogue of output row 2*te + o (results in `res`): mask (BWD), statistics, 8-byte stores.  `live` = te >= 0.
+    // epilogue of output row 2*te + o (results in `res`): mask (BWD), statistics, one 16-byte store.  `live` = te >= 0.
     auto epilogue = [&](int te, int o, bool live) {
         const unsigned soff = live ? (unsigned)((b * H + 2 * te + o) * W) * 128u : 0u;
-        const bool pv = pvalid && live;
+        bf16x8 v = __builtin_shufflevector(res[o][0], res[o][1], 0, 1, 2, 3, 4, 5, 6, 7);   // channels ch8 .. ch8 + 7
+        if (BWD) {
+            const bf16x8 yv = *reinterpret_cast<const bf16x8*>(smem + YBASE + ((te + NSY) % NSY) * 2 * SLOT + o * SLOT + px * 128 + ch8 * 2);
+            float sc[8], sh[8];
+            load8f(reinterpret_cast<const float*>(smem + FBASE) + ch8, sc);
+            load8f(reinterpret_cast<const float*>(smem + FBASE + 256) + ch8, sh);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            bf16x4 v = res[o][j];
-            if (BWD) {
-                const int ch0 = 32 * nh + 16 * j + 4 * g;
-                const bf16x4 yv = *reinterpret_cast<const bf16x4*>(smem + YBASE + ((te + NSY) % NSY) * 2 * SLOT + o * SLOT + px * 128 + ch0 * 2);
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + FBASE + ch0 * 4);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(smem + FBASE + 256 + ch0 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // (`res` is zero for pad pixels and before the first step, and the y ring is finite there:
-                    // zero DMA fill, or the staged filter - no selects on the sums)
-                    const float yf = bf2f(yv[e]);
-                    const bool on = bn_affine(yf, sc[e], sh[e]) > 0.f;
-                    v[e] = on ? v[e] : f2bf(0.f);
-                    const float gg = bf2f(v[e]);
-                    s1[j][e] += gg; s2[j][e] += gg * yf;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float f = bf2f(v[e]);
-                    s1[j][e] += f; s2[j][e] += f * f;
-                }
+            for (int e = 0; e < 8; ++e) {
+                // (`res` is zero for pad pixels and before the first step, and the y ring is finite there:
+                // zero DMA fill, or the staged filter - no selects on the sums)
+                const float yf = bf2f(yv[e]);
+                const bool on = bn_affine(yf, sc[e], sh[e]) > 0.f;
+                v[e] = on ? v[e] : f2bf(0.f);
+                const float gg = bf2f(v[e]);
+                s1[e >> 2][e & 3] += gg; s2[e >> 2][e & 3] += gg * yf;
             }
-            gstore8(yr, pv ? ov[j] : INVALID, soff, __builtin_bit_cast(u32x2, v));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(v[e]);
+                s1[e >> 2][e & 3] += f; s2[e >> 2][e & 3] += f * f;
+            }
         }
+        gstore16(yr, live ? ov : INVALID, soff, __builtin_bit_cast(u32x4, v));
     };
 
 #ifdef DDL_CROWS_PROBE
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ch = 32 * nh + 16 * j + 4 * g + e;
+                const int ch = ch8 + 4 * j + e;
                 red[mg * 64 + ch] = s1[j][e];
                 red[256 + mg * 64 + ch] = s2[j][e];
             }

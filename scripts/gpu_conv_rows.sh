@@ -5,7 +5,7 @@ OUT=gpurun_out/${TAG:-conv_rows}
 mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
 timeout -k 10 300 python -u -m pytest tests/test_gpu_kernels.py -x -q -k "conv_rows3x3 or conv_fwd_bwd" --timeout 120 --timeout-method thread 2>&1 | tail -3 || exit 1
-if [ -f benchmarks/native/_ddl_kernels_probe.so ]; then
+if [ -f benchmarks/native/_ddl_kernels_probe.so ] && [ -z "$NOPROBE" ]; then
 DDL_KERNELS_SO=$PWD/benchmarks/native/_ddl_kernels_probe.so timeout -k 10 120 python -u benchmarks/conv_rows_phases.py || exit 1
 fi
 export TMPDIR=/tmp
