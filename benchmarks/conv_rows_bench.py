@@ -31,6 +31,11 @@ x = torch.randn((B, 64, 56, 56), device=DEV).to(BF).contiguous(memory_format=CL)
 w = (torch.randn((64, 64, 3, 3), device=DEV) / 24.0).to(BF).contiguous(memory_format=CL)
 yp = torch.randn((B, 64, 56, 56), device=DEV).to(BF).contiguous(memory_format=CL)
 fco = torch.stack([torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.3]).contiguous()
+y_out, z_out, st = torch.empty_like(x), torch.empty_like(x), torch.empty((B, 2, 64), device=DEV)
+if K.conv_rows3x3_ok(64, 64, 3, 3, 1, 1, 56, 56):
+    xf = timeit(lambda: K.conv_rows3x3(x, w, y_out, stats=st, in_fcoef=fco, z_out=z_out))
+    ap = timeit(lambda: K.bn_apply_fwd(x, fco[0], fco[1], None, z_out, B * 56 * 56, 64, True))
+    print("forward with the BatchNorm apply of the layer in front inside: %.1f us; that apply pass alone: %.1f us" % (xf, ap), flush=True)
 with torch.no_grad():
     f = timeit(lambda: hip._conv_fwd(x, w, 1, 1, True))
     b = timeit(lambda: hip._conv_dgrad_bn(x, w, x.shape, 1, 1, yp, fco.data_ptr()))

@@ -37,6 +37,8 @@ struct RowsParams {
     float* stats;           // [B][2][64] or null
     const bf16_t* ep_y;     // BWD: [B][H][56][64]
     const float* ep_fcoef;  // BWD: [2][64] forward scale | shift
+    const float* in_fcoef;  // XF: [2][64] scale | shift of the BatchNorm in FRONT of this conv: x is its raw input
+    bf16_t* z_out;          // XF: [B][H][56][64] receives relu(scale * x + shift), the tensor the conv consumes
     int B, H;
     unsigned bytes;         // of one activation tensor
 };
@@ -54,14 +56,21 @@ __device__ __forceinline__ void gstore16(u32x4 rsrc, unsigned voff, unsigned sof
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <bool BWD>
+// XF (forward only): the input is the RAW output of the previous conv; BatchNorm apply + ReLU of the layer in between
+// happen here, in LDS, on every row once after it has landed (each element is then read by nine taps) and the
+// transformed rows are also written out (the weight gradient of this conv reads them): the separate apply pass - a
+// read and a write of the whole tensor on the dependent chain - disappears.  One more ring stage: rows land two steps
+// ahead, are transformed one step ahead and read from the next step on; halo pixels and rows stay zero.
+template <bool BWD, bool XF = false>
 __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
+    static_assert(!(BWD && XF), "the input transform belongs to the forward form");
     constexpr int W = 56, C = 64;
-    constexpr int NSX = 8, NSY = 4;                               // x row slots; y groups (two rows each)
+    constexpr int LEAD = XF ? 3 : 2;                              // the DMA of group t + LEAD is issued in step t
+    constexpr int NSX = 2 * LEAD + 4, NSY = 4;                    // x row slots; y groups (two rows each)
     constexpr int SLOT = 8192, XBYTES = NSX * SLOT + 256;         // + 256: the last tile's tap reads run 2 pixels past its slot
     constexpr int WBYTES = 64 * 9 * C * 2;                        // the whole filter, staged once
     constexpr int YBASE = XBYTES;                                 // y ring (BWD) - the filter's staging area before the loop
-    constexpr int FBASE = YBASE + WBYTES, FBYTES = BWD ? 512 : 0;
+    constexpr int FBASE = YBASE + WBYTES, FBYTES = (BWD || XF) ? 512 : 0;
     static_assert(NSY * 2 * SLOT <= WBYTES, "the y ring lives in the filter's staging area");
     constexpr int NPW = BWD ? 4 : 2;                              // DMA instructions per wave and step
 #ifndef DDL_CROWS_ISSUE_AT
@@ -89,6 +98,7 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
 
     const u32x4 xr = raw_rsrc(p.x, p.bytes), yr = raw_rsrc(p.y, p.bytes);
     const u32x4 er = raw_rsrc(BWD ? p.ep_y : p.x, p.bytes), wr = raw_rsrc(p.w, WBYTES);
+    const u32x4 zr = raw_rsrc(XF ? p.z_out : p.y, p.bytes);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
 
     // ---- DMA geometry.  A wave moves pieces q0, q0+1 (8 pixels each) of row (wid >> 2) of the step's two rows.
@@ -125,10 +135,33 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
     // ---- prologue: the filter (72 pieces of 1 KiB, 9 per wave) and the first six x rows are fetched together
 #pragma unroll
     for (int i = 0; i < 9; ++i) lds_dma16(wr, lds0 + (unsigned)(YBASE + (wid + 8 * i) * 1024), (unsigned)((wid + 8 * i) * 1024 + lane * 16), 0u);
-    issue_x(-1);
-    issue_x(0);
-    issue_x(1);
-    if (BWD && tid < 128) reinterpret_cast<float*>(smem + FBASE)[tid] = p.ep_fcoef[tid];
+#pragma unroll
+    for (int k = -1; k < LEAD; ++k) issue_x(k);
+    if ((BWD || XF) && tid < 128) reinterpret_cast<float*>(smem + FBASE)[tid] = (XF ? p.in_fcoef : p.ep_fcoef)[tid];
+
+    // ---- XF: a thread's chunk of a landed row: pixel tid / 8, physical chunk tid % 8 (1 KiB contiguous per wave)
+    const int tj = tid >> 3, tlc = (tid & 7) ^ ((tj >> 1) & 7);             // logical chunk = channels 8 tlc ..
+    const bool tvalid = tj >= 1 && tj <= W;
+    auto transform = [&](int k, int r) {
+        {
+            const int v = 2 * k + 2 + r;
+            if (v < 1 || v > H) return;                                     // uniform: zero rows stay zero
+            if (tvalid) {
+                unsigned char* a = smem + ((v + NSX) % NSX) * SLOT + tid * 16;
+                bf16x8 d = *reinterpret_cast<const bf16x8*>(a);
+                float sc[8], sh[8];
+                load8f(reinterpret_cast<const float*>(smem + FBASE) + 8 * tlc, sc);
+                load8f(reinterpret_cast<const float*>(smem + FBASE + 256) + 8 * tlc, sh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bn_affine(bf2f(d[e]), sc[e], sh[e]);     // (the forward apply kernel's rounding)
+                    d[e] = f2bf(f > 0.f ? f : 0.f);
+                }
+                *reinterpret_cast<bf16x8*>(a) = d;
+                gstore16(zr, (unsigned)(((tj - 1) * C + 8 * tlc) * 2), (unsigned)((b * H + v - 1) * W) * 128u, __builtin_bit_cast(u32x4, d));
+            }
+        }
+    };
 
     // ---- fragment read offsets inside a row slot: [s][channel half]
     int xo[3][2];
@@ -166,6 +199,12 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
         __builtin_amdgcn_s_barrier();
         issue_y(0);
         issue_y(1);
+    }
+    if (XF) {       // the rows of step 0 (groups -1 and 0); group t+1 follows inside step t
+        transform(-1, 0); transform(-1, 1);
+        transform(0, 0); transform(0, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     if (PRIO == 2 && nh == 1) __builtin_amdgcn_s_setprio(1);
@@ -237,7 +276,7 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) f[s][h] = *reinterpret_cast<const bf16x8*>(row + xo[s][h]);
             if (i == ISSUE_AT) {   // (behind this row's fragment reads: the DMA's "memory" clobber pins LDS reads)
-                issue_x(t + 2);
+                issue_x(t + LEAD);
                 if (BWD) issue_y(t + 2);
             }
 #pragma unroll
@@ -254,6 +293,10 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
             }
             if (i == 0) epilogue(t - 1, 0, t > 0);
             if (i == 1) epilogue(t - 1, 1, t > 0);
+            // XF: the rows of group t+1 landed before the last barrier and are read from the next step on: their
+            // transform sits between the multiplies like the epilogue
+            if (XF && i == 1) transform(t + 1, 0);
+            if (XF && i == 3) transform(t + 1, 1);
         }
 #pragma unroll
         for (int o = 0; o < 2; ++o)
@@ -326,9 +369,13 @@ extern "C" int ddl_conv_rows3x3_ok(int C, int N, int R, int S, int stride, int p
 
 // y = conv3x3(x, w) for dense NHWC [B][H][56][64] tensors; `stats` ([B][2][64] fp32, may be null): per image
 // sum y | sum y^2 (forward) or, with `ep_y` / `ep_fcoef`, sum g | sum g*ep_y of the masked gradient g that is stored
+// `in_fcoef` + `z_out` (forward only): x is the raw input of a BatchNorm + ReLU in front of this conv ([2][64] scale |
+// shift); the conv consumes relu(scale * x + shift) and also writes it to `z_out`
 extern "C" int ddl_conv_rows3x3(const void* x, const void* w, void* y, void* stats, const void* ep_y, const void* ep_fcoef,
-                                int B, int H, int W, int C, int N, hipStream_t stream) {
+                                const void* in_fcoef, void* z_out, int B, int H, int W, int C, int N, hipStream_t stream) {
     if (!x || !w || !y || B <= 0) return DDL_EINVAL;
+    if ((in_fcoef == nullptr) != (z_out == nullptr) || (in_fcoef && ep_y)) return DDL_EINVAL;
+    if (in_fcoef && (!ddl_aligned16(in_fcoef) || !ddl_aligned16(z_out))) return DDL_EALIGN;
     if (!ddl_conv_rows3x3_ok(C, N, 3, 3, 1, 1, H, W)) return DDL_EINVAL;
     if ((ep_y == nullptr) != (ep_fcoef == nullptr) || (ep_y && !stats)) return DDL_EINVAL;
     if (!ddl_aligned16(x) || !ddl_aligned16(w) || !ddl_aligned16(y) || (ep_y && !ddl_aligned16(ep_y)) ||
@@ -338,8 +385,10 @@ extern "C" int ddl_conv_rows3x3(const void* x, const void* w, void* y, void* sta
     RowsParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.stats = (float*)stats;
     p.ep_y = (const bf16_t*)ep_y; p.ep_fcoef = (const float*)ep_fcoef;
+    p.in_fcoef = (const float*)in_fcoef; p.z_out = (bf16_t*)z_out;
     p.B = B; p.H = H; p.bytes = (unsigned)bytes;
-    if (ep_y) DDL_KLAUNCH((conv_rows3x3_kernel<true>), dim3(B), dim3(512), 0, stream, p);
+    if (in_fcoef) DDL_KLAUNCH((conv_rows3x3_kernel<false, true>), dim3(B), dim3(512), 0, stream, p);
+    else if (ep_y) DDL_KLAUNCH((conv_rows3x3_kernel<true>), dim3(B), dim3(512), 0, stream, p);
     else DDL_KLAUNCH((conv_rows3x3_kernel<false>), dim3(B), dim3(512), 0, stream, p);
     return ddl_launch_status();
 }

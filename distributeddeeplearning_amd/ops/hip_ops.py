@@ -272,6 +272,9 @@ def _flush_notifications():
 
 
 # ---- raw (autograd-free) building blocks -------------------------------------------------------
+import os as _os_rows
+
+
 def _rows_ok(x, w, stride, padding):
     """The row-streaming 3x3 kernel serves this conv (dense NHWC input, dense [K][3][3][C] filter)."""
     if w.dim() != 4 or x.dim() != 4:
@@ -280,6 +283,28 @@ def _rows_ok(x, w, stride, padding):
     Kc, _, R, S = w.shape
     return K.conv_rows3x3_ok(C, Kc, R, S, stride, padding, H, W) and \
         x.stride() == (H * W * C, 1, W * C, C) and x.numel() * 2 < (1 << 31) - 1
+
+
+# BatchNorm apply + ReLU of a bottleneck's FIRST unit inside the row-streaming 3x3 conv that follows it
+# (DDL_CONV_ROWS_BN_IN=1).  Measured and left off: the kernel still has to write the activated tensor out (the weight
+# gradient reads it), so it turns bandwidth-bound - 92 us against 65 us + a 37 us apply pass, 16.72 vs 16.73 ms per
+# step (profiles/r3_notes.md section 19); the form that never materialises the tensor needs the same transform in
+# the weight-gradient kernel.
+_ROWS_BN_IN = _os_rows.environ.get("DDL_CONV_ROWS_BN_IN", "0") == "1"
+
+
+def _rows_bn_in_ok(x, w, stride, padding, w_next, stride_next, pad_next):
+    """Unit (x, w) is a conv whose BatchNorm + ReLU output only feeds the next conv (w_next), and that conv is
+    served by the row-streaming kernel on this unit's output shape."""
+    if w.dim() != 4 or w_next.dim() != 4:
+        return False
+    B, C, H, W = x.shape
+    Kc, _, R, S = w.shape
+    Ho = (H + 2 * padding - R) // stride + 1
+    Wo = (W + 2 * padding - S) // stride + 1
+    Kn, Cn, Rn, Sn = w_next.shape
+    return Cn == Kc and K.conv_rows3x3_ok(Kc, Kn, Rn, Sn, stride_next, pad_next, Ho, Wo) and \
+        B * Ho * Wo * Kc * 2 < (1 << 31) - 1
 
 
 def _conv_fwd(x, w, stride, padding, want_stats):
@@ -612,7 +637,7 @@ def _bn_bwd(dz, y, z, gamma, coeffs, relu, want_g, beta=None, has_res=True, part
 # allocation or a view) is 3-5 us of host time, ~30 of them per layer and step, and the host has
 # to keep ahead of ~50 us kernels in the late layers (profiles/r1_notes.md).
 def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentum, eps, relu,
-              apply=True, res_coeffs=None, bits=None, keep=None):
+              apply=True, res_coeffs=None, bits=None, keep=None, xf=None):
     """Training-mode conv -> BatchNorm(+residual)(+ReLU).  Returns (y, z, coeffs[4, C]).
     ``apply=False`` stops after the statistics (z is None): the caller folds this BatchNorm into
     a later kernel.  ``res_coeffs``: coefficient block of such a deferred BatchNorm whose raw conv
@@ -633,7 +658,12 @@ def _unit_fwd(x, w, stride, padding, gamma, beta, residual, rmean, rvar, momentu
     tmp = torch.empty(2 * T * Kc + 4 * P * Kc, dtype=torch.float32, device=dev)
     st = tmp.data_ptr()
     wk = st + 8 * T * Kc if P else None      # fp64 fold workspace (8-byte aligned: T*Kc*8 bytes in)
-    if rows:
+    if xf is not None:
+        # x is the RAW output of the previous unit's conv (its BatchNorm was left unapplied): the row-streaming
+        # kernel applies scale / shift / ReLU to the rows it has staged and writes them out on the side
+        in_coeffs, z_in = xf
+        K.conv_rows3x3(x, w, y, stats=st, in_fcoef=in_coeffs.data_ptr() + 8 * C, z_out=z_in)
+    elif rows:
         K.conv_rows3x3(x, w, y, stats=st)
     else:
         K.conv_igemm(x, _geom(x), w, y, Kc, R, S, stride, padding, padding, 1, Ho, Wo, stats=st)
@@ -1287,6 +1317,7 @@ class ResidualBlockFn(Function):
                                        False)
         cur = x
         zbits_out = None
+        xf_pending = None
         ctx.lin_pre = ctx.lin_pre_ds = ctx.lin_xs = None
         # cfg[9] (grad_premasked) is only set by residual_chain with grad mode on: backward will receive a
         # pre-masked gradient and the BatchNorm partials, i.e. it will take the linear path
@@ -1307,9 +1338,21 @@ class ResidualBlockFn(Function):
                     zbits_out = zbits
                 if last and ds_raw is not None:   # the residual add reads the projection's output
                     K.stream_wait_stream(K._raw_stream(), ds_raw, _SIDE["event"])
-                y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, shortcut if last else None,
-                                    rm, rv, momentum, eps, True,
-                                    res_coeffs=cd if (last and has_ds) else None, bits=zbits)
+                if xf_pending is not None:
+                    # the previous unit stopped after its statistics: this conv applies that BatchNorm + ReLU itself
+                    z_prev = torch.empty_like(xf_pending[0])
+                    y, z, c = _unit_fwd(xf_pending[0], w, strides[i], pads[i], g, b, shortcut if last else None,
+                                        rm, rv, momentum, eps, True, bits=zbits, xf=(xf_pending[1], z_prev))
+                    saved_z[-1] = z_prev
+                    xf_pending = None
+                elif _ROWS_BN_IN and units == 3 and i == 0 and not last and \
+                        _rows_bn_in_ok(cur, w, strides[i], pads[i], groups[1][0], strides[1], pads[1]):
+                    y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, None, rm, rv, momentum, eps, True, apply=False)
+                    xf_pending = (y, c)
+                else:
+                    y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, shortcut if last else None,
+                                        rm, rv, momentum, eps, True,
+                                        res_coeffs=cd if (last and has_ds) else None, bits=zbits)
             else:
                 y, st = _conv_fwd(cur, w, strides[i], pads[i], training)
                 z, c = _bn_fwd(y, g, b, shortcut if last else None, st, rm, rv, training,
@@ -1322,7 +1365,7 @@ class ResidualBlockFn(Function):
                 # this block's last BatchNorm will go by linearity in backward: its Gram part only
                 # needs z (the narrow activation just written) and runs now, on the idle side stream
                 ctx.lin_pre = _bn3_linear_gram_forward(z, groups[units - 1][0])
-            cur = z
+            cur = z if xf_pending is None else y     # (a pending unit hands its raw conv output on)
         if len(cfg) > 11 and cfg[11] is not None:
             cfg[11].y = saved_y[-1]
             cfg[11].y2 = yd if (has_ds and training) else None

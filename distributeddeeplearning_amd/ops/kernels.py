@@ -331,11 +331,13 @@ def conv_rows3x3_ok(C, N, R, S, stride, pad, H, W):
     return bool(lib().ddl_conv_rows3x3_ok(_i32(C), _i32(N), _i32(R), _i32(S), _i32(stride), _i32(pad), _i32(H), _i32(W)))
 
 
-def conv_rows3x3(x, w, y, stats=None, ep_y=None, ep_fcoef=None, stream=None):
+def conv_rows3x3(x, w, y, stats=None, ep_y=None, ep_fcoef=None, stream=None, in_fcoef=None, z_out=None):
     """y = conv3x3(x, w), stride 1, pad 1, for dense NHWC [B, 64, H, 56] tensors and a [64][3][3][64] filter.
     ``stats`` ([B][2][64] fp32, tensor or raw address): per-image sum y | sum y^2; with ``ep_y`` + ``ep_fcoef``
     (backward-data of a layer behind BatchNorm + ReLU) y is the masked gradient g and the table holds
-    sum g | sum g*ep_y."""
+    sum g | sum g*ep_y.  ``in_fcoef`` ([2][64] fp32 scale | shift, tensor or raw address) + ``z_out`` (forward):
+    ``x`` is the RAW input of a BatchNorm + ReLU in front of this conv; the kernel applies them to the rows it has
+    staged, convolves the result and also writes it to ``z_out``."""
     B, C, H, W = x.shape
     N = y.shape[1]
     if tuple(y.shape) != (B, N, H, W) or not conv_rows3x3_ok(C, N, 3, 3, 1, 1, H, W):
@@ -349,9 +351,11 @@ def conv_rows3x3(x, w, y, stats=None, ep_y=None, ep_fcoef=None, stream=None):
         raise KernelError("conv_rows3x3: statistics table needs one row per image")
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append(("conv_rows", B, H, W, C, H, W, N, 3, 3, 1, 1, B * H * W, int(ep_y is not None)))
-    f = _fn("ddl_conv_rows3x3", "pppppp iiiii p")
-    check(f(x.data_ptr(), w.data_ptr(), y.data_ptr(), _p(stats), _p(ep_y), _p(ep_fcoef), B, H, W, C, N,
-            _raw_stream() if stream is None else stream), "conv_rows3x3")
+    if z_out is not None and (tuple(z_out.shape) != (B, C, H, W) or z_out.stride() != x.stride()):
+        raise KernelError("conv_rows3x3: z_out must look like the input")
+    f = _fn("ddl_conv_rows3x3", "pppppp pp iiiii p")
+    check(f(x.data_ptr(), w.data_ptr(), y.data_ptr(), _p(stats), _p(ep_y), _p(ep_fcoef), _p(in_fcoef), _p(z_out),
+            B, H, W, C, N, _raw_stream() if stream is None else stream), "conv_rows3x3")
 
 
 @functools.lru_cache(maxsize=None)

@@ -1163,3 +1163,30 @@ def test_gram_weight_gradient_emits_column_sums(B, C2, hw):
     assert torch.allclose(cs[:, 0].sum(0), zf.sum(0), rtol=1e-4)
     assert torch.equal(cs[:, 0], cs[:, 1])
     assert relerr(slabs.sum(0), zf.t() @ zf) < 1e-3
+
+
+def test_conv_rows3x3_applies_the_batchnorm_in_front_of_it():
+    """Row-streaming 3x3 kernel with the input transform: x is the raw output of the previous conv, the kernel applies
+    scale / shift / ReLU to the staged rows, convolves them and writes them out - against the separate apply pass."""
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    K.require()
+    B, H = 3, 56
+    if not K.conv_rows3x3_ok(64, 64, 3, 3, 1, 1, H, 56):
+        pytest.skip("row-streaming kernel switched off")
+    y0 = rand_nhwc(B, 64, H, 56, seed=31)
+    w = (torch.randn((64, 64, 3, 3), device=DEV) / 24.0).to(BF).contiguous(memory_format=CL)
+    fco = torch.stack([torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.3]).contiguous()
+    # reference: the library's own apply pass, then the plain row-streaming conv
+    z_ref = torch.empty_like(y0)
+    K.bn_apply_fwd(y0, fco[0], fco[1], None, z_ref, B * H * 56, 64, True)
+    y_ref = torch.empty_like(y0)
+    st_ref = torch.empty((B, 2, 64), device=DEV)
+    K.conv_rows3x3(z_ref, w, y_ref, stats=st_ref)
+    z = torch.full_like(y0, float("nan"))
+    y = torch.full_like(y0, float("nan"))
+    st = torch.full((B, 2, 64), float("nan"), device=DEV)
+    K.conv_rows3x3(y0, w, y, stats=st, in_fcoef=fco, z_out=z)
+    assert torch.equal(z, z_ref)          # same rounding as the apply kernel: the backward mask is re-derived from it
+    assert torch.equal(y, y_ref)
+    assert torch.equal(st, st_ref)
