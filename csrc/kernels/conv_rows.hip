@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
 
     const u32x4 xr = raw_rsrc(p.x, p.bytes), yr = raw_rsrc(p.y, p.bytes);
     const u32x4 er = raw_rsrc(BWD ? p.ep_y : p.x, p.bytes), wr = raw_rsrc(p.w, WBYTES);
-    const u32x4 zr = raw_rsrc(XF ? p.z_out : p.y, p.bytes);
+    const u32x4 zr = raw_rsrc(XF && p.z_out ? p.z_out : p.y, XF && p.z_out ? p.bytes : 0u);   // (no z_out: zero records)
+    const bool zstore = XF && p.z_out != nullptr;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
 
     // ---- DMA geometry.  A wave moves pieces q0, q0+1 (8 pixels each) of row (wid >> 2) of the step's two rows.
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
                     d[e] = f2bf(f > 0.f ? f : 0.f);
                 }
                 *reinterpret_cast<bf16x8*>(a) = d;
-                gstore16(zr, (unsigned)(((tj - 1) * C + 8 * tlc) * 2), (unsigned)((b * H + v - 1) * W) * 128u, __builtin_bit_cast(u32x4, d));
+                if (zstore) gstore16(zr, (unsigned)(((tj - 1) * C + 8 * tlc) * 2), (unsigned)((b * H + v - 1) * W) * 128u, __builtin_bit_cast(u32x4, d));
             }
         }
     };
@@ -369,13 +370,13 @@ extern "C" int ddl_conv_rows3x3_ok(int C, int N, int R, int S, int stride, int p
 
 // y = conv3x3(x, w) for dense NHWC [B][H][56][64] tensors; `stats` ([B][2][64] fp32, may be null): per image
 // sum y | sum y^2 (forward) or, with `ep_y` / `ep_fcoef`, sum g | sum g*ep_y of the masked gradient g that is stored
-// `in_fcoef` + `z_out` (forward only): x is the raw input of a BatchNorm + ReLU in front of this conv ([2][64] scale |
-// shift); the conv consumes relu(scale * x + shift) and also writes it to `z_out`
+// `in_fcoef` (forward only): x is the raw input of a BatchNorm + ReLU in front of this conv ([2][64] scale | shift);
+// the conv consumes relu(scale * x + shift) and, with `z_out`, also writes it out
 extern "C" int ddl_conv_rows3x3(const void* x, const void* w, void* y, void* stats, const void* ep_y, const void* ep_fcoef,
                                 const void* in_fcoef, void* z_out, int B, int H, int W, int C, int N, hipStream_t stream) {
     if (!x || !w || !y || B <= 0) return DDL_EINVAL;
-    if ((in_fcoef == nullptr) != (z_out == nullptr) || (in_fcoef && ep_y)) return DDL_EINVAL;
-    if (in_fcoef && (!ddl_aligned16(in_fcoef) || !ddl_aligned16(z_out))) return DDL_EALIGN;
+    if ((z_out && !in_fcoef) || (in_fcoef && ep_y)) return DDL_EINVAL;
+    if (in_fcoef && (!ddl_aligned16(in_fcoef) || (z_out && !ddl_aligned16(z_out)))) return DDL_EALIGN;
     if (!ddl_conv_rows3x3_ok(C, N, 3, 3, 1, 1, H, W)) return DDL_EINVAL;
     if ((ep_y == nullptr) != (ep_fcoef == nullptr) || (ep_y && !stats)) return DDL_EINVAL;
     if (!ddl_aligned16(x) || !ddl_aligned16(w) || !ddl_aligned16(y) || (ep_y && !ddl_aligned16(ep_y)) ||

@@ -39,6 +39,9 @@ struct WgradParams {
     // layout of a statistics table: bn_colsum_fold sums it) - the matrix pipe adds them up on the side (a row of
     // ones as a 17th "output channel" fragment), so the Gram launch of the linear path needs no extra pass over x
     float* colsum;
+    // Row-streaming kernel, XF form: x is the RAW output of the conv in front; its BatchNorm apply + ReLU
+    // ([2][C] scale | shift) happen on the staged rows (the activated tensor is never materialised)
+    const float* x_fcoef;
 };
 
 __device__ __forceinline__ u32x4 wg_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -602,12 +605,14 @@ __global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p)
 // so tap offsets are compile-time immediates.  Pad pixels (56..63) have dy = 0 (range check) and read a clamped,
 // finite x pixel.  Swizzle: 32-byte window w of pixel P at window w ^ f(P), f = (P >> 1) & 3 for 128-byte
 // pixels, P & 7 for 256-byte pixels (as in the tile kernels), applied to the DMA source and to the reads.
-template <int C, int RS>
+template <int C, int RS, bool XF = false>
 __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams p, int imgs_per_split, int B) {
     constexpr int XB = C * 2, XW = XB / 32, CF = C / 16, CL = CF / 4;
     constexpr int NST = 3, XROWS = RS + 2, DYOFF = XROWS * 8192, STAGE = DYOFF + 8192, NP = XROWS + 1;
     static_assert(C == 64 || C == 128, "16-channel groups over four waves");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
+    static_assert(!XF || (C == 64 && RS == 1), "input transform: the 64-channel, 56-pixel-row layers");
+    constexpr int FBASE = NST * STAGE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE + (XF ? 512 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid >> 2, wc = wid & 3;
@@ -738,10 +743,44 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams 
                     acc[i][t9][cl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[t9][cl], acc[i][t9][cl], 0, 0, 0);
     };
 
+    // XF: scale * x + shift, ReLU on the x rows of a landed stage, in place, before anybody reads fragments from it
+    // (one more barrier per step; halo pixels and rows outside the image stay zero).  A thread owns pixel tid / 8,
+    // physical 16-byte chunk tid % 8 of each of the three rows.
+    const int tP = tid >> 3, tchp = tid & 7;
+    const int tlch = ((((tchp >> 1) ^ ((tP >> 1) & 3))) << 1) | (tchp & 1);          // logical chunk: channels 8 tlch ..
+    const bool tvalid = tP >= 1 && tP <= W;
+    if (XF && tid < 128) reinterpret_cast<float*>(smem + FBASE)[tid] = p.x_fcoef[tid];
+    auto transform = [&](int t, int stage) {
+        if (t >= T) return;
+        const int h0 = (t % SPI) * RS;
+        float sc[8], sh[8];
+        load8f(reinterpret_cast<const float*>(smem + FBASE) + 8 * tlch, sc);
+        load8f(reinterpret_cast<const float*>(smem + FBASE + 256) + 8 * tlch, sh);
+#pragma unroll
+        for (int i = 0; i < XROWS; ++i) {
+            const int hin = h0 - 1 + i;
+            if (hin < 0 || hin >= H || !tvalid) continue;
+            unsigned char* a = smem + stage * STAGE + i * 8192 + tid * 16;
+            bf16x8 d = *reinterpret_cast<const bf16x8*>(a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bn_affine(bf2f(d[e]), sc[e], sh[e]);
+                d[e] = f2bf(f > 0.f ? f : 0.f);
+            }
+            *reinterpret_cast<bf16x8*>(a) = d;
+        }
+    };
+
     fetch(0, 0);
     fetch(1, 1);
     wait_steps(1);
+    if (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the coefficient stores)
     __builtin_amdgcn_s_barrier();
+    if (XF) {
+        transform(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     int cur = 0, nxt = 2;
     // (Measured and dropped, profiles/r3_notes.md: a two-phase schedule with the two waves of a SIMD one phase
     // apart - one reads fragments while the other multiplies - 75 -> 95 us; the second wave group issuing its DMA
@@ -758,6 +797,11 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams 
         __builtin_amdgcn_s_barrier();
         nxt = cur;
         cur = cur + 1 == NST ? 0 : cur + 1;
+        if (XF) {                               // the stage of step t+1 has landed everywhere
+            transform(t + 1, cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -1041,10 +1085,30 @@ extern "C" int ddl_conv_wgrad_colsum_ok(long long M, int K, int C) {
 
 // `colsum` (optional; plain GEMMs whose tile shape has the instantiation - ddl_conv_wgrad_colsum_ok): [splits][2][C]
 // fp32 column sums of x per split (a statistics-table layout, both rows alike)
+// the row-streaming kernel will serve this weight gradient (what a caller that relies on `x_fcoef` has to know)
+extern "C" int ddl_conv_wgrad_rows_ok(int K, int C, int R, int S, int Hout, int Wout, int stride, int B) {
+    return wgrad_rows(K, C, R, S, Hout, Wout, stride, B) ? 1 : 0;
+}
+
+// `x_fcoef` (optional, [2][C] fp32 scale | shift; only where the row-streaming kernel with C = 64 on 56-pixel rows
+// serves the launch - anything else is refused): x is the raw input of a BatchNorm + ReLU, applied on the staged rows
+extern "C" int ddl_conv_wgrad_ex2(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
+                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                  int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
+                                  void* colsum, const void* x_fcoef, hipStream_t stream);
+
 extern "C" int ddl_conv_wgrad_ex(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
                                  int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
                                  void* colsum, hipStream_t stream) {
+    return ddl_conv_wgrad_ex2(dy, x, partial, dy_numel, x_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout, K, R, S,
+                              stride, pad, pad_w, splits, colsum, nullptr, stream);
+}
+
+extern "C" int ddl_conv_wgrad_ex2(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
+                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                  int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
+                                  void* colsum, const void* x_fcoef, hipStream_t stream) {
     if (!dy || !x || !partial || B <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || splits <= 0) return DDL_EINVAL;
     if (C % 8 != 0 || K % 8 != 0) return DDL_EINVAL;
     if (dy_numel <= 0 || x_numel <= 0) return DDL_EINVAL;
@@ -1069,6 +1133,8 @@ extern "C" int ddl_conv_wgrad_ex(const void* dy, const void* x, void* partial, l
     p.m_per_split = (int)mps;
     p.il_sg = p.il_mg = 0;
     p.colsum = (float*)colsum;
+    p.x_fcoef = (const float*)x_fcoef;
+    if (x_fcoef && !ddl_aligned16(x_fcoef)) return DDL_EALIGN;
     // 32-bit offsets inside one split: its dy rows, and the images its x rows come from
     if ((mps + 64) * K * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     if ((mps / ((long long)Hout * Wout) + 3) * xs_b * 2 >= 0x7fffffffLL || (mps + 64) * xs_w * 2 >= 0x7fffffffLL) return DDL_EINVAL;
@@ -1081,12 +1147,17 @@ extern "C" int ddl_conv_wgrad_ex(const void* dy, const void* x, void* partial, l
         const int ips = wgrad_rows_ips(K, B);
         if (splits != (B + ips - 1) / ips) return DDL_EINVAL;   // the workspace was sized by ddl_conv_wgrad_splits_ex
         dim3 grid(splits * (K / 64)), block(512);
-        if (C == 64 && Wout == 56) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1>), grid, block, 0, stream, p, ips, B);
+        if (p.x_fcoef) {
+            if (!(C == 64 && Wout == 56)) return DDL_EINVAL;
+            DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1, true>), grid, block, 0, stream, p, ips, B);
+        }
+        else if (C == 64 && Wout == 56) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1>), grid, block, 0, stream, p, ips, B);
         else if (C == 64) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 2>), grid, block, 0, stream, p, ips, B);
         else if (Wout == 56) DDL_KLAUNCH((conv_wgrad_rows_kernel<128, 1>), grid, block, 0, stream, p, ips, B);
         else DDL_KLAUNCH((conv_wgrad_rows_kernel<128, 2>), grid, block, 0, stream, p, ips, B);
         return ddl_launch_status();
     }
+    if (x_fcoef) return DDL_EINVAL;            // only the row-streaming kernel transforms its input
     if (wgrad_big(M, K, C, R, S)) {
         static const int nst = getenv("DDL_WGRAD_BIG_NST") ? atoi(getenv("DDL_WGRAD_BIG_NST")) : 3;  // tuning knob
         p.tiles_k = K / 256;

@@ -188,7 +188,7 @@ def _is_stem(w, stride, padding):
 
 
 def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho, Wo, n_valid=None,
-                accumulate=False, stream=None, workspace=None):
+                accumulate=False, stream=None, workspace=None, x_fcoef=None):
     """Backward-weights: split-K partials then ordered reduction into a tensor shaped like
     ``w_like`` (memory [K][R][S][C]).  ``stream`` (raw handle) / ``workspace`` (callable: bytes ->
     device address valid on that stream): the side-stream path, which neither switches torch's
@@ -202,7 +202,7 @@ def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho
     else:
         partial = workspace(4 * splits * slab)
     K.conv_wgrad(dy, x_ptr_tensor, geom, partial, Kc, R, S, stride, pad, pad_w, Ho, Wo, splits,
-                 stream=stream)
+                 stream=stream, x_fcoef=x_fcoef)
     n = slab if n_valid is None else n_valid
     K.splitk_reduce(partial, w_like, n, splits, slab, accumulate, stream=stream)
     return w_like
@@ -285,12 +285,12 @@ def _rows_ok(x, w, stride, padding):
         x.stride() == (H * W * C, 1, W * C, C) and x.numel() * 2 < (1 << 31) - 1
 
 
-# BatchNorm apply + ReLU of a bottleneck's FIRST unit inside the row-streaming 3x3 conv that follows it
-# (DDL_CONV_ROWS_BN_IN=1).  Measured and left off: the kernel still has to write the activated tensor out (the weight
-# gradient reads it), so it turns bandwidth-bound - 92 us against 65 us + a 37 us apply pass, 16.72 vs 16.73 ms per
-# step (profiles/r3_notes.md section 19); the form that never materialises the tensor needs the same transform in
-# the weight-gradient kernel.
-_ROWS_BN_IN = _os_rows.environ.get("DDL_CONV_ROWS_BN_IN", "0") == "1"
+# BatchNorm apply + ReLU of a bottleneck's FIRST unit inside the row-streaming kernels that consume it (the 3x3 conv in
+# forward, that conv's weight gradient in backward): DDL_CONV_ROWS_BN_IN = 2 (default) the activated tensor is never
+# written - its only two readers transform the raw conv output on the rows they stage in LDS; 1 = the forward conv
+# transforms and also writes the tensor out for a plain weight gradient (bandwidth-bound: breaks even); 0 = separate
+# apply pass.  16.75 -> 16.69 ms per step, bit-identical training (profiles/r3_notes.md section 19).
+_ROWS_BN_IN = int(_os_rows.environ.get("DDL_CONV_ROWS_BN_IN", "2"))
 
 
 def _rows_bn_in_ok(x, w, stride, padding, w_next, stride_next, pad_next):
@@ -406,7 +406,7 @@ def _side_prewait(device):
     return True
 
 
-def _conv_wgrad(dy, x, w, stride, padding, prewaited=False):
+def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None):
     """dw for ``w``: written into ``w.grad`` when that is a live arena view (returns None and
     notifies the listeners), otherwise returned as a new tensor.
 
@@ -420,7 +420,7 @@ def _conv_wgrad(dy, x, w, stride, padding, prewaited=False):
         side = _side_stream(dy.device) if (_SIDE["on"] and Ho * Wo < _SIDE_MAX_HW) else None
         if side is None:
             _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                        accumulate=True)
+                        accumulate=True, x_fcoef=x_fcoef)
         else:
             # raw event + raw stream handle: no torch stream context, no torch Event objects and a
             # persistent partial-sum workspace (side-stream kernels run in order, one buffer
@@ -430,12 +430,12 @@ def _conv_wgrad(dy, x, w, stride, padding, prewaited=False):
                 if not prewaited:
                     K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
                 _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                            accumulate=True, stream=raw, workspace=_side_workspace)
+                            accumulate=True, stream=raw, workspace=_side_workspace, x_fcoef=x_fcoef)
             else:  # torch's own stream switch and events (DDL_SIDE_LEAN=0)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                                accumulate=True)
+                                accumulate=True, x_fcoef=x_fcoef)
             # The side stream reads dy and x after this function returns.  They are kept alive
             # until the join at the end of backward instead of `record_stream`: blocks with a
             # recorded stream are withheld from reuse until that stream has passed an event, and
@@ -454,7 +454,7 @@ def _conv_wgrad(dy, x, w, stride, padding, prewaited=False):
         _notify(w)
         return None
     return _wgrad_into(dy, x, _geom(x), torch.empty_like(w), Kc, R, S, stride, padding, padding,
-                       Ho, Wo)
+                       Ho, Wo, x_fcoef=x_fcoef)
 
 
 # ---- second stream for weight gradients --------------------------------------------------------
@@ -1340,15 +1340,20 @@ class ResidualBlockFn(Function):
                     K.stream_wait_stream(K._raw_stream(), ds_raw, _SIDE["event"])
                 if xf_pending is not None:
                     # the previous unit stopped after its statistics: this conv applies that BatchNorm + ReLU itself
-                    z_prev = torch.empty_like(xf_pending[0])
+                    z_prev = torch.empty_like(xf_pending[0]) if xf_pending[2] else None
                     y, z, c = _unit_fwd(xf_pending[0], w, strides[i], pads[i], g, b, shortcut if last else None,
                                         rm, rv, momentum, eps, True, bits=zbits, xf=(xf_pending[1], z_prev))
-                    saved_z[-1] = z_prev
+                    saved_z[-1] = z_prev      # (None: backward hands the raw tensor + coefficients to the weight gradient)
                     xf_pending = None
                 elif _ROWS_BN_IN and units == 3 and i == 0 and not last and \
                         _rows_bn_in_ok(cur, w, strides[i], pads[i], groups[1][0], strides[1], pads[1]):
                     y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, None, rm, rv, momentum, eps, True, apply=False)
-                    xf_pending = (y, c)
+                    # (2: only where the row-streaming weight gradient will serve the next conv in backward)
+                    wn = groups[1][0]
+                    full = _ROWS_BN_IN == 2 and wn.requires_grad and \
+                        _grad_listeners is not None and _DIRECT["on"] and _direct_grad_ok(wn) and \
+                        K.conv_wgrad_rows_ok(wn.shape[0], wn.shape[1], 3, 3, y.shape[2], y.shape[3], 1, y.shape[0])
+                    xf_pending = (y, c, not full)
                 else:
                     y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, shortcut if last else None,
                                         rm, rv, momentum, eps, True,
@@ -1427,6 +1432,12 @@ class ResidualBlockFn(Function):
             else:
                 mask = 1 if last else 2
             inp = zs[i - 1] if i > 0 else x
+            inp_fcoef = None
+            if i > 0 and inp is None:
+                # the previous unit's activated output was never written (DDL_CONV_ROWS_BN_IN=2): the weight
+                # gradient gets the raw conv output and that BatchNorm's scale / shift
+                inp = ys[i - 1]
+                inp_fcoef = cs[i - 1].data_ptr() + 8 * inp.shape[1]
             if last and i > 0 and mask == 0 and fused is not None and _FUSE_BN_REDUCE["on"] and \
                     _bn3_linear_ok(w, strides[i], pads[i], dz, inp):
                 # the wide unit by linearity: its dy never exists (see _bn3_linear_dgrad)
@@ -1461,7 +1472,7 @@ class ResidualBlockFn(Function):
                                                cs[i - 1].data_ptr() + 8 * inp.shape[1])
                 else:
                     dz, fused = _conv_dgrad(dy, w, inp.shape, strides[i], pads[i]), None
-                dw = _conv_wgrad(dy, inp, w, strides[i], pads[i], prewaited=pre)
+                dw = _conv_wgrad(dy, inp, w, strides[i], pads[i], prewaited=pre, x_fcoef=inp_fcoef)
                 put(i, dw, dg, db)
                 _flush_notifications()  # the chain's next kernel is queued: now talk to the exchange
             else:

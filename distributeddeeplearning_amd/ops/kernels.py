@@ -379,19 +379,27 @@ def conv_wgrad_colsum_ok(M, K, C):
     return bool(lib().ddl_conv_wgrad_colsum_ok(_i64(M), _i32(K), _i32(C)))
 
 
+@functools.lru_cache(maxsize=None)
+def conv_wgrad_rows_ok(K, C, R, S, Hout, Wout, stride, B):
+    """True when the row-streaming weight-gradient kernel serves this (dense, < 2 GiB) problem."""
+    return bool(lib().ddl_conv_wgrad_rows_ok(_i32(K), _i32(C), _i32(R), _i32(S), _i32(Hout), _i32(Wout), _i32(stride), _i32(B)))
+
+
 def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hout, Wout, splits,
-               stream=None, colsum=None):
+               stream=None, colsum=None, x_fcoef=None):
     """``partial``: tensor or raw address; ``stream``: raw HIP stream (default: current).  ``colsum`` (raw address
     or tensor, plain GEMMs with :func:`conv_wgrad_colsum_ok`): receives [splits][2][C] fp32 column sums of x per
-    split, both rows alike - a statistics-table layout that :func:`bn_colsum_fold` sums."""
+    split, both rows alike - a statistics-table layout that :func:`bn_colsum_fold` sums.  ``x_fcoef`` ([2][C] fp32
+    scale | shift, raw address or tensor; only where :func:`conv_wgrad_rows_ok` and C = 64 on 56-pixel rows): ``x``
+    is the RAW input of a BatchNorm + ReLU whose output is the conv's real input - applied on the staged rows."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
     if _PROBE_SKIP_WGRAD == "all" or (_PROBE_SKIP_WGRAD == "late" and Hout <= 14) or (_PROBE_SKIP_WGRAD == "early" and Hout > 14):
         return   # timing probe only (gradients are garbage): what the step costs without these launches
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append(("conv_wgrad", B, Hin, Win, C, Hout, Wout, K, R, S, stride, 1, dy.numel() // K, splits))
-    f = _fn("ddl_conv_wgrad_ex", "ppp qq iiii qqq iiiiiiiii p p")
+    f = _fn("ddl_conv_wgrad_ex2", "ppp qq iiii qqq iiiiiiiii pp p")
     check(f(dy.data_ptr(), x_ptr_tensor.data_ptr(), _p(partial), dy.numel(), xn, B, Hin, Win,
-            C, sb, sh, sw, Hout, Wout, K, R, S, stride, pad, pad_w, splits, _p(colsum),
+            C, sb, sh, sw, Hout, Wout, K, R, S, stride, pad, pad_w, splits, _p(colsum), _p(x_fcoef),
             _raw_stream() if stream is None else stream), "conv_wgrad")
 
 

@@ -1190,3 +1190,18 @@ def test_conv_rows3x3_applies_the_batchnorm_in_front_of_it():
     assert torch.equal(z, z_ref)          # same rounding as the apply kernel: the backward mask is re-derived from it
     assert torch.equal(y, y_ref)
     assert torch.equal(st, st_ref)
+    # ... and without writing the activated tensor at all
+    y2 = torch.full_like(y0, float("nan"))
+    K.conv_rows3x3(y0, w, y2, stats=st, in_fcoef=fco)
+    assert torch.equal(y2, y_ref)
+    # the row-streaming weight gradient applies the same transform to the rows it stages
+    from distributeddeeplearning_amd.ops import hip_ops as hip
+
+    if K.conv_wgrad_rows_ok(64, 64, 3, 3, H, 56, 1, B):
+        dy = rand_nhwc(B, 64, H, 56, seed=32)
+        splits = K.conv_wgrad_splits(B * H * 56, 64, 64, 3, 3, H, 56, 1, B)
+        s_ref = torch.empty((splits, 64 * 9 * 64), device=DEV)
+        s_xf = torch.full_like(s_ref, float("nan"))
+        K.conv_wgrad(dy, z_ref, hip._geom(z_ref), s_ref, 64, 3, 3, 1, 1, 1, H, 56, splits)
+        K.conv_wgrad(dy, y0, hip._geom(y0), s_xf, 64, 3, 3, 1, 1, 1, H, 56, splits, x_fcoef=fco)
+        assert torch.equal(s_xf, s_ref)
