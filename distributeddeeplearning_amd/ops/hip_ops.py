@@ -1342,10 +1342,12 @@ class ResidualBlockFn(Function):
                     # the previous unit stopped after its statistics: this conv applies that BatchNorm + ReLU itself
                     z_prev = torch.empty_like(xf_pending[0]) if xf_pending[2] else None
                     y, z, c = _unit_fwd(xf_pending[0], w, strides[i], pads[i], g, b, shortcut if last else None,
-                                        rm, rv, momentum, eps, True, bits=zbits, xf=(xf_pending[1], z_prev))
+                                        rm, rv, momentum, eps, True,
+                                        res_coeffs=cd if (last and has_ds) else None, bits=zbits,
+                                        xf=(xf_pending[1], z_prev))
                     saved_z[-1] = z_prev      # (None: backward hands the raw tensor + coefficients to the weight gradient)
                     xf_pending = None
-                elif _ROWS_BN_IN and units == 3 and i == 0 and not last and \
+                elif _ROWS_BN_IN and units >= 2 and i == 0 and not last and \
                         _rows_bn_in_ok(cur, w, strides[i], pads[i], groups[1][0], strides[1], pads[1]):
                     y, z, c = _unit_fwd(cur, w, strides[i], pads[i], g, b, None, rm, rv, momentum, eps, True, apply=False)
                     # (2: only where the row-streaming weight gradient will serve the next conv in backward)
