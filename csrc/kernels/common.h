@@ -36,6 +36,12 @@ __device__ __forceinline__ void load8f(const float* p, float* v) {
 // rounding on both sides, so "z > 0" can be re-derived from y without reading z.
 __device__ __forceinline__ float bn_affine(float v, float sc, float sh) { return __builtin_fmaf(v, sc, sh); }
 
+// The one BatchNorm-backward apply dy = ca*g + cb*y + cc: explicit operation order, so that the kernels which fold
+// the apply into their own input staging (conv_rows.hip, conv_wgrad.hip) round exactly like the separate pass.
+__device__ __forceinline__ float bn_bwd_affine(float g, float y, float ca, float cb, float cc) {
+    return __builtin_fmaf(ca, g, __builtin_fmaf(cb, y, cc));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

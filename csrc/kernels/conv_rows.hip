@@ -39,6 +39,8 @@ struct RowsParams {
     const float* ep_fcoef;  // BWD: [2][64] forward scale | shift
     const float* in_fcoef;  // XF: [2][64] scale | shift of the BatchNorm in FRONT of this conv: x is its raw input
     bf16_t* z_out;          // XF: [B][H][56][64] receives relu(scale * x + shift), the tensor the conv consumes
+    const bf16_t* dy_y;     // DYF: [B][H][56][64] the raw output of the conv whose gradient x is to become
+    const float* dy_coef;   // DYF: [3][64] ca | cb | cc of that BatchNorm's backward: the conv consumes ca*x + cb*dy_y + cc
     int B, H;
     unsigned bytes;         // of one activation tensor
 };
@@ -61,18 +63,29 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // transformed rows are also written out (the weight gradient of this conv reads them): the separate apply pass - a
 // read and a write of the whole tensor on the dependent chain - disappears.  One more ring stage: rows land two steps
 // ahead, are transformed one step ahead and read from the next step on; halo pixels and rows stay zero.
-template <bool BWD, bool XF = false>
+//
+// DYF (backward-data only): the input is the gradient g2 with respect to a BatchNorm's OUTPUT and `dy_y` that
+// BatchNorm's input; the gradient the conv consumes, ca*g2 + cb*y2 + cc, is formed here in LDS (the backward apply
+// pass - read two tensors, write one, on the dependent chain - disappears together with its output; the weight
+// gradient of the same conv does the same on its own rows, conv_wgrad.hip).  The rows of y2 ride in a third ring next
+// to their x rows (same pixel layout and swizzle: a thread's chunk has the same offset in both); a landed group is
+// transformed in place behind the step's barrier and a second barrier follows (LDS has no room for the extra
+// ring stage that lets the forward form hide its transform between the multiplies): x 64 + y2 32 + y_prev 48 KB.
+template <bool BWD, bool XF = false, bool DYF = false>
 __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
     static_assert(!(BWD && XF), "the input transform belongs to the forward form");
+    static_assert(!DYF || BWD, "the gradient transform belongs to the backward-data form");
     constexpr int W = 56, C = 64;
     constexpr int LEAD = XF ? 3 : 2;                              // the DMA of group t + LEAD is issued in step t
-    constexpr int NSX = 2 * LEAD + 4, NSY = 4;                    // x row slots; y groups (two rows each)
+    constexpr int NSX = 2 * LEAD + 4, NSY = DYF ? 3 : 4;          // x row slots; y_prev groups (two rows each)
+    constexpr int YLEAD = DYF ? 1 : 2;                            // y_prev group t + YLEAD is issued in step t (read in step t + YLEAD + 1)
     constexpr int SLOT = 8192, XBYTES = NSX * SLOT + 256;         // + 256: the last tile's tap reads run 2 pixels past its slot
     constexpr int WBYTES = 64 * 9 * C * 2;                        // the whole filter, staged once
-    constexpr int YBASE = XBYTES;                                 // y ring (BWD) - the filter's staging area before the loop
-    constexpr int FBASE = YBASE + WBYTES, FBYTES = (BWD || XF) ? 512 : 0;
-    static_assert(NSY * 2 * SLOT <= WBYTES, "the y ring lives in the filter's staging area");
-    constexpr int NPW = BWD ? 4 : 2;                              // DMA instructions per wave and step
+    constexpr int Y2BASE = XBYTES, Y2BYTES = DYF ? 4 * SLOT : 0;  // DYF: y2 ring, two groups
+    constexpr int YBASE = Y2BASE + Y2BYTES;                       // y_prev ring (BWD)
+    constexpr int RINGS = Y2BYTES + (BWD ? NSY * 2 * SLOT : 0);   // the filter's staging area before the loop lies over both
+    constexpr int FBASE = Y2BASE + (RINGS > WBYTES ? RINGS : WBYTES), FBYTES = DYF ? 1280 : (BWD || XF) ? 512 : 0;
+    constexpr int NPW = DYF ? 6 : BWD ? 4 : 2;                    // DMA instructions per wave and step
 #ifndef DDL_CROWS_ISSUE_AT
 #define DDL_CROWS_ISSUE_AT 2
 #endif
@@ -99,6 +112,7 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
     const u32x4 xr = raw_rsrc(p.x, p.bytes), yr = raw_rsrc(p.y, p.bytes);
     const u32x4 er = raw_rsrc(BWD ? p.ep_y : p.x, p.bytes), wr = raw_rsrc(p.w, WBYTES);
     const u32x4 zr = raw_rsrc(XF && p.z_out ? p.z_out : p.y, XF && p.z_out ? p.bytes : 0u);   // (no z_out: zero records)
+    const u32x4 y2r = raw_rsrc(DYF ? p.dy_y : p.x, p.bytes);
     const bool zstore = XF && p.z_out != nullptr;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
 
@@ -123,6 +137,15 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
         lds_dma16(xr, dst, ok ? xv[0] : INVALID, soff);
         lds_dma16(xr, dst + 1024, ok ? xv[1] : INVALID, soff);
     };
+    // DYF: the y2 rows of the same group, laid out like their x rows; group k lives in ring half k & 1
+    auto issue_y2 = [&](int k) {
+        const int v = 2 * k + 2 + r2;
+        const bool ok = v >= 1 && v <= H;
+        const unsigned soff = ok ? (unsigned)((b * H + v - 1) * W) * 128u : 0u;
+        const unsigned dst = lds0 + (unsigned)(Y2BASE + ((k & 1) * 2 + r2) * SLOT + q0 * 1024);
+        lds_dma16(y2r, dst, ok ? xv[0] : INVALID, soff);
+        lds_dma16(y2r, dst + 1024, ok ? xv[1] : INVALID, soff);
+    };
     // BWD: the y_prev rows of step k (output rows 2k, 2k+1)
     auto issue_y = [&](int k) {
         const int row = 2 * k + r2;
@@ -135,10 +158,11 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
 
     // ---- prologue: the filter (72 pieces of 1 KiB, 9 per wave) and the first six x rows are fetched together
 #pragma unroll
-    for (int i = 0; i < 9; ++i) lds_dma16(wr, lds0 + (unsigned)(YBASE + (wid + 8 * i) * 1024), (unsigned)((wid + 8 * i) * 1024 + lane * 16), 0u);
+    for (int i = 0; i < 9; ++i) lds_dma16(wr, lds0 + (unsigned)(Y2BASE + (wid + 8 * i) * 1024), (unsigned)((wid + 8 * i) * 1024 + lane * 16), 0u);
 #pragma unroll
     for (int k = -1; k < LEAD; ++k) issue_x(k);
     if ((BWD || XF) && tid < 128) reinterpret_cast<float*>(smem + FBASE)[tid] = (XF ? p.in_fcoef : p.ep_fcoef)[tid];
+    if (DYF && tid < 192) reinterpret_cast<float*>(smem + FBASE + 512)[tid] = p.dy_coef[tid];
 
     // ---- XF: a thread's chunk of a landed row: pixel tid / 8, physical chunk tid % 8 (1 KiB contiguous per wave)
     const int tj = tid >> 3, tlc = (tid & 7) ^ ((tj >> 1) & 7);             // logical chunk = channels 8 tlc ..
@@ -161,6 +185,27 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
                 *reinterpret_cast<bf16x8*>(a) = d;
                 if (zstore) gstore16(zr, (unsigned)(((tj - 1) * C + 8 * tlc) * 2), (unsigned)((b * H + v - 1) * W) * 128u, __builtin_bit_cast(u32x4, d));
             }
+        }
+    };
+
+    // DYF: row r of landed group k becomes ca * g + cb * y2 + cc, in place (halo pixels and rows outside stay zero)
+    auto transform_dy = [&](int k, int r) {
+        const int v = 2 * k + 2 + r;
+        if (v < 1 || v > H) return;                                         // uniform
+        if (tvalid) {
+            unsigned char* a = smem + ((v + NSX) % NSX) * SLOT + tid * 16;
+            bf16x8 d = *reinterpret_cast<const bf16x8*>(a);
+            const bf16x8 y2 = *reinterpret_cast<const bf16x8*>(smem + Y2BASE + ((k & 1) * 2 + r) * SLOT + tid * 16);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {        // (four channels at a time: the filter leaves few registers)
+                const float* co = reinterpret_cast<const float*>(smem + FBASE + 512) + 8 * tlc + 4 * hh;
+                const f32x4 ca = *reinterpret_cast<const f32x4*>(co), cb = *reinterpret_cast<const f32x4*>(co + 64),
+                            cc = *reinterpret_cast<const f32x4*>(co + 128);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    d[4 * hh + e] = f2bf(bn_bwd_affine(bf2f(d[4 * hh + e]), bf2f(y2[4 * hh + e]), ca[e], cb[e], cc[e]));
+            }
+            *reinterpret_cast<bf16x8*>(a) = d;
         }
     };
 
@@ -191,7 +236,7 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                wreg[tap][h][j] = *reinterpret_cast<const bf16x8*>(smem + YBASE + (((32 * nh + 8 * (col >> 2) + 4 * j + (col & 3)) * 9 + tap) * C + 32 * h + 8 * g) * 2);
+                wreg[tap][h][j] = *reinterpret_cast<const bf16x8*>(smem + Y2BASE + (((32 * nh + 8 * (col >> 2) + 4 * j + (col & 3)) * 9 + tap) * C + 32 * h + 8 * g) * 2);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)   // (complete before the staging area is reused)
         asm volatile("" : "+v"(wreg[tap][0][0]), "+v"(wreg[tap][0][1]), "+v"(wreg[tap][1][0]), "+v"(wreg[tap][1][1]));
@@ -199,7 +244,19 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         issue_y(0);
-        issue_y(1);
+        if (DYF) issue_y(-1);       // (zero rows: the slot the idle epilogue of step 0 reads lies outside the staged filter)
+        else issue_y(1);
+    }
+    if (DYF) {      // the rows of step 0 (groups -1 and 0); group t+1 follows behind the barrier of step t
+        issue_y2(-1);
+        issue_y2(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        transform_dy(-1, 0); transform_dy(-1, 1);
+        transform_dy(0, 0); transform_dy(0, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_y2(1);
     }
     if (XF) {       // the rows of step 0 (groups -1 and 0); group t+1 follows inside step t
         transform(-1, 0); transform(-1, 1);
@@ -278,7 +335,8 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
                 for (int h = 0; h < 2; ++h) f[s][h] = *reinterpret_cast<const bf16x8*>(row + xo[s][h]);
             if (i == ISSUE_AT) {   // (behind this row's fragment reads: the DMA's "memory" clobber pins LDS reads)
                 issue_x(t + LEAD);
-                if (BWD) issue_y(t + 2);
+                if (DYF) issue_y2(t + LEAD);
+                if (BWD) issue_y(t + YLEAD);
             }
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
@@ -313,6 +371,11 @@ __global__ void __launch_bounds__(512) conv_rows3x3_kernel(const RowsParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         CROWS_STAMP(1);
         __builtin_amdgcn_s_barrier();
+        if (DYF) {
+            transform_dy(t + 1, 0); transform_dy(t + 1, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         CROWS_STAMP(2);
     }
     epilogue(T - 1, 0, true);
@@ -372,10 +435,16 @@ extern "C" int ddl_conv_rows3x3_ok(int C, int N, int R, int S, int stride, int p
 // sum y | sum y^2 (forward) or, with `ep_y` / `ep_fcoef`, sum g | sum g*ep_y of the masked gradient g that is stored
 // `in_fcoef` (forward only): x is the raw input of a BatchNorm + ReLU in front of this conv ([2][64] scale | shift);
 // the conv consumes relu(scale * x + shift) and, with `z_out`, also writes it out
+// `dy_y` + `dy_coef` (backward-data only, i.e. with `ep_y`): x is the gradient with respect to a BatchNorm's output,
+// dy_y that BatchNorm's input and dy_coef its backward coefficients [3][64] ca | cb | cc; the conv consumes
+// ca * x + cb * dy_y + cc (rounded to bf16 like the separate apply pass)
 extern "C" int ddl_conv_rows3x3(const void* x, const void* w, void* y, void* stats, const void* ep_y, const void* ep_fcoef,
-                                const void* in_fcoef, void* z_out, int B, int H, int W, int C, int N, hipStream_t stream) {
+                                const void* in_fcoef, void* z_out, const void* dy_y, const void* dy_coef,
+                                int B, int H, int W, int C, int N, hipStream_t stream) {
     if (!x || !w || !y || B <= 0) return DDL_EINVAL;
     if ((z_out && !in_fcoef) || (in_fcoef && ep_y)) return DDL_EINVAL;
+    if ((dy_y == nullptr) != (dy_coef == nullptr) || (dy_y && !ep_y)) return DDL_EINVAL;
+    if (dy_y && (!ddl_aligned16(dy_y) || !ddl_aligned16(dy_coef))) return DDL_EALIGN;
     if (in_fcoef && (!ddl_aligned16(in_fcoef) || (z_out && !ddl_aligned16(z_out)))) return DDL_EALIGN;
     if (!ddl_conv_rows3x3_ok(C, N, 3, 3, 1, 1, H, W)) return DDL_EINVAL;
     if ((ep_y == nullptr) != (ep_fcoef == nullptr) || (ep_y && !stats)) return DDL_EINVAL;
@@ -387,8 +456,10 @@ extern "C" int ddl_conv_rows3x3(const void* x, const void* w, void* y, void* sta
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.stats = (float*)stats;
     p.ep_y = (const bf16_t*)ep_y; p.ep_fcoef = (const float*)ep_fcoef;
     p.in_fcoef = (const float*)in_fcoef; p.z_out = (bf16_t*)z_out;
+    p.dy_y = (const bf16_t*)dy_y; p.dy_coef = (const float*)dy_coef;
     p.B = B; p.H = H; p.bytes = (unsigned)bytes;
     if (in_fcoef) DDL_KLAUNCH((conv_rows3x3_kernel<false, true>), dim3(B), dim3(512), 0, stream, p);
+    else if (dy_y) DDL_KLAUNCH((conv_rows3x3_kernel<true, false, true>), dim3(B), dim3(512), 0, stream, p);
     else if (ep_y) DDL_KLAUNCH((conv_rows3x3_kernel<true>), dim3(B), dim3(512), 0, stream, p);
     else DDL_KLAUNCH((conv_rows3x3_kernel<false>), dim3(B), dim3(512), 0, stream, p);
     return ddl_launch_status();

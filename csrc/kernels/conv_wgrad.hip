@@ -42,6 +42,8 @@ struct WgradParams {
     // Row-streaming kernel, XF form: x is the RAW output of the conv in front; its BatchNorm apply + ReLU
     // ([2][C] scale | shift) happen on the staged rows (the activated tensor is never materialised)
     const float* x_fcoef;
+    const bf16_t* dy_y;      // row-streaming kernel, K = 64: dy is the gradient w.r.t. a BatchNorm's OUTPUT, dy_y that
+    const float* dy_coef;    // BatchNorm's input, dy_coef [3][64] ca | cb | cc: the kernel multiplies ca*dy + cb*dy_y + cc
 };
 
 __device__ __forceinline__ u32x4 wg_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -605,14 +607,17 @@ __global__ void __launch_bounds__(512) conv_wgrad256_kernel(const WgradParams p)
 // so tap offsets are compile-time immediates.  Pad pixels (56..63) have dy = 0 (range check) and read a clamped,
 // finite x pixel.  Swizzle: 32-byte window w of pixel P at window w ^ f(P), f = (P >> 1) & 3 for 128-byte
 // pixels, P & 7 for 256-byte pixels (as in the tile kernels), applied to the DMA source and to the reads.
-template <int C, int RS, bool XF = false>
+// DYF: the BatchNorm-backward apply of the layer behind this conv (dy = ca*g + cb*y + cc) happens on the landed dy
+// tile, like XF on the x rows: the tile of y rides next to the tile of g and the materialised dy never exists (the
+// backward-data kernel of the same conv does the same, conv_rows.hip).
+template <int C, int RS, bool XF = false, bool DYF = false>
 __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams p, int imgs_per_split, int B) {
     constexpr int XB = C * 2, XW = XB / 32, CF = C / 16, CL = CF / 4;
-    constexpr int NST = 3, XROWS = RS + 2, DYOFF = XROWS * 8192, STAGE = DYOFF + 8192, NP = XROWS + 1;
+    constexpr int NST = 3, XROWS = RS + 2, DYOFF = XROWS * 8192, STAGE = DYOFF + 8192 + (DYF ? 8192 : 0), NP = XROWS + 1 + (DYF ? 1 : 0);
     static_assert(C == 64 || C == 128, "16-channel groups over four waves");
-    static_assert(!XF || (C == 64 && RS == 1), "input transform: the 64-channel, 56-pixel-row layers");
+    static_assert(!(XF || DYF) || (C == 64 && RS == 1), "input transforms: the 64-channel, 56-pixel-row layers");
     constexpr int FBASE = NST * STAGE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE + (XF ? 512 : 0)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE + (DYF ? 1280 : XF ? 512 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid >> 2, wc = wid & 3;
@@ -632,6 +637,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams 
     const int T = (b_end - b_begin) * SPI;
 
     const u32x4 dyr = raw_rsrc(p.dy, (unsigned)p.dy_bytes), xr = raw_rsrc(p.x, (unsigned)p.x_bytes);
+    const u32x4 dy2r = raw_rsrc(DYF ? p.dy_y : p.dy, (unsigned)p.dy_bytes);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     constexpr unsigned INVALID = 0x80000000u;
 
@@ -664,6 +670,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams 
         }
         const unsigned dsoff = (unsigned)(((b * H + h0) * W) * p.K + kh * 64) * 2u;
         lds_dma16(dyr, sb + DYOFF, live ? dy_lane : INVALID, dsoff);
+        if (DYF) lds_dma16(dy2r, sb + DYOFF + 8192, live ? dy_lane : INVALID, dsoff);
     };
     auto wait_steps = [&](int steps_in_flight) {
         if (steps_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
@@ -750,23 +757,40 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams 
     const int tlch = ((((tchp >> 1) ^ ((tP >> 1) & 3))) << 1) | (tchp & 1);          // logical chunk: channels 8 tlch ..
     const bool tvalid = tP >= 1 && tP <= W;
     if (XF && tid < 128) reinterpret_cast<float*>(smem + FBASE)[tid] = p.x_fcoef[tid];
+    if (DYF && tid < 192) reinterpret_cast<float*>(smem + FBASE + 512)[tid] = p.dy_coef[tid];
+    // DYF: the same thread owns pixel tid / 8, physical chunk tid % 8 of the dy tile (its swizzle: dy_lane above)
+    const int dlch = ((((tchp >> 1) ^ ((tP >> 1) & 3))) << 1) | (tchp & 1);
     auto transform = [&](int t, int stage) {
         if (t >= T) return;
-        const int h0 = (t % SPI) * RS;
-        float sc[8], sh[8];
-        load8f(reinterpret_cast<const float*>(smem + FBASE) + 8 * tlch, sc);
-        load8f(reinterpret_cast<const float*>(smem + FBASE + 256) + 8 * tlch, sh);
+        if (XF) {
+            const int h0 = (t % SPI) * RS;
+            float sc[8], sh[8];
+            load8f(reinterpret_cast<const float*>(smem + FBASE) + 8 * tlch, sc);
+            load8f(reinterpret_cast<const float*>(smem + FBASE + 256) + 8 * tlch, sh);
 #pragma unroll
-        for (int i = 0; i < XROWS; ++i) {
-            const int hin = h0 - 1 + i;
-            if (hin < 0 || hin >= H || !tvalid) continue;
-            unsigned char* a = smem + stage * STAGE + i * 8192 + tid * 16;
-            bf16x8 d = *reinterpret_cast<const bf16x8*>(a);
+            for (int i = 0; i < XROWS; ++i) {
+                const int hin = h0 - 1 + i;
+                if (hin < 0 || hin >= H || !tvalid) continue;
+                unsigned char* a = smem + stage * STAGE + i * 8192 + tid * 16;
+                bf16x8 d = *reinterpret_cast<const bf16x8*>(a);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = bn_affine(bf2f(d[e]), sc[e], sh[e]);
-                d[e] = f2bf(f > 0.f ? f : 0.f);
+                for (int e = 0; e < 8; ++e) {
+                    const float f = bn_affine(bf2f(d[e]), sc[e], sh[e]);
+                    d[e] = f2bf(f > 0.f ? f : 0.f);
+                }
+                *reinterpret_cast<bf16x8*>(a) = d;
             }
+        }
+        if (DYF && tP < RS * W) {                   // pad pixels keep their zero gradient
+            unsigned char* a = smem + stage * STAGE + DYOFF + tid * 16;
+            bf16x8 d = *reinterpret_cast<const bf16x8*>(a);
+            const bf16x8 y2 = *reinterpret_cast<const bf16x8*>(a + 8192);
+            float ca[8], cb[8], cc[8];
+            load8f(reinterpret_cast<const float*>(smem + FBASE + 512) + 8 * dlch, ca);
+            load8f(reinterpret_cast<const float*>(smem + FBASE + 768) + 8 * dlch, cb);
+            load8f(reinterpret_cast<const float*>(smem + FBASE + 1024) + 8 * dlch, cc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = f2bf(bn_bwd_affine(bf2f(d[e]), bf2f(y2[e]), ca[e], cb[e], cc[e]));
             *reinterpret_cast<bf16x8*>(a) = d;
         }
     };
@@ -774,9 +798,9 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams 
     fetch(0, 0);
     fetch(1, 1);
     wait_steps(1);
-    if (XF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the coefficient stores)
+    if (XF || DYF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the coefficient stores)
     __builtin_amdgcn_s_barrier();
-    if (XF) {
+    if (XF || DYF) {
         transform(0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -797,7 +821,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const WgradParams 
         __builtin_amdgcn_s_barrier();
         nxt = cur;
         cur = cur + 1 == NST ? 0 : cur + 1;
-        if (XF) {                               // the stage of step t+1 has landed everywhere
+        if (XF || DYF) {                        // the stage of step t+1 has landed everywhere
             transform(t + 1, cur);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1096,6 +1120,12 @@ extern "C" int ddl_conv_wgrad_ex2(const void* dy, const void* x, void* partial, 
                                   int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
                                   int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
                                   void* colsum, const void* x_fcoef, hipStream_t stream);
+// ... and `dy_y` + `dy_coef` ([3][K] fp32 ca | cb | cc; same kernel, K = 64): dy is the gradient with respect to a
+// BatchNorm's output and dy_y that BatchNorm's input - the product uses ca*dy + cb*dy_y + cc (backward apply folded in)
+extern "C" int ddl_conv_wgrad_ex3(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
+                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                  int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
+                                  void* colsum, const void* x_fcoef, const void* dy_y, const void* dy_coef, hipStream_t stream);
 
 extern "C" int ddl_conv_wgrad_ex(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
@@ -1109,6 +1139,16 @@ extern "C" int ddl_conv_wgrad_ex2(const void* dy, const void* x, void* partial, 
                                   int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
                                   int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
                                   void* colsum, const void* x_fcoef, hipStream_t stream) {
+    return ddl_conv_wgrad_ex3(dy, x, partial, dy_numel, x_numel, B, Hin, Win, C, xs_b, xs_h, xs_w, Hout, Wout, K, R, S,
+                              stride, pad, pad_w, splits, colsum, x_fcoef, nullptr, nullptr, stream);
+}
+
+extern "C" int ddl_conv_wgrad_ex3(const void* dy, const void* x, void* partial, long long dy_numel, long long x_numel,
+                                  int B, int Hin, int Win, int C, long long xs_b, long long xs_h, long long xs_w,
+                                  int Hout, int Wout, int K, int R, int S, int stride, int pad, int pad_w, int splits,
+                                  void* colsum, const void* x_fcoef, const void* dy_y, const void* dy_coef, hipStream_t stream) {
+    if ((dy_y == nullptr) != (dy_coef == nullptr)) return DDL_EINVAL;
+    if (dy_y && (!ddl_aligned16(dy_y) || !ddl_aligned16(dy_coef))) return DDL_EALIGN;
     if (!dy || !x || !partial || B <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || splits <= 0) return DDL_EINVAL;
     if (C % 8 != 0 || K % 8 != 0) return DDL_EINVAL;
     if (dy_numel <= 0 || x_numel <= 0) return DDL_EINVAL;
@@ -1135,6 +1175,7 @@ extern "C" int ddl_conv_wgrad_ex2(const void* dy, const void* x, void* partial, 
     p.colsum = (float*)colsum;
     p.x_fcoef = (const float*)x_fcoef;
     if (x_fcoef && !ddl_aligned16(x_fcoef)) return DDL_EALIGN;
+    p.dy_y = (const bf16_t*)dy_y; p.dy_coef = (const float*)dy_coef;
     // 32-bit offsets inside one split: its dy rows, and the images its x rows come from
     if ((mps + 64) * K * 2 >= 0x7fffffffLL) return DDL_EINVAL;
     if ((mps / ((long long)Hout * Wout) + 3) * xs_b * 2 >= 0x7fffffffLL || (mps + 64) * xs_w * 2 >= 0x7fffffffLL) return DDL_EINVAL;
@@ -1147,9 +1188,11 @@ extern "C" int ddl_conv_wgrad_ex2(const void* dy, const void* x, void* partial, 
         const int ips = wgrad_rows_ips(K, B);
         if (splits != (B + ips - 1) / ips) return DDL_EINVAL;   // the workspace was sized by ddl_conv_wgrad_splits_ex
         dim3 grid(splits * (K / 64)), block(512);
-        if (p.x_fcoef) {
-            if (!(C == 64 && Wout == 56)) return DDL_EINVAL;
-            DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1, true>), grid, block, 0, stream, p, ips, B);
+        if (p.x_fcoef || p.dy_y) {
+            if (!(C == 64 && Wout == 56) || (p.dy_y && K != 64)) return DDL_EINVAL;
+            if (p.x_fcoef && p.dy_y) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1, true, true>), grid, block, 0, stream, p, ips, B);
+            else if (p.dy_y) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1, false, true>), grid, block, 0, stream, p, ips, B);
+            else DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1, true>), grid, block, 0, stream, p, ips, B);
         }
         else if (C == 64 && Wout == 56) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 1>), grid, block, 0, stream, p, ips, B);
         else if (C == 64) DDL_KLAUNCH((conv_wgrad_rows_kernel<64, 2>), grid, block, 0, stream, p, ips, B);
@@ -1157,7 +1200,7 @@ extern "C" int ddl_conv_wgrad_ex2(const void* dy, const void* x, void* partial, 
         else DDL_KLAUNCH((conv_wgrad_rows_kernel<128, 2>), grid, block, 0, stream, p, ips, B);
         return ddl_launch_status();
     }
-    if (x_fcoef) return DDL_EINVAL;            // only the row-streaming kernel transforms its input
+    if (x_fcoef || dy_y) return DDL_EINVAL;    // only the row-streaming kernel transforms its inputs
     if (wgrad_big(M, K, C, R, S)) {
         static const int nst = getenv("DDL_WGRAD_BIG_NST") ? atoi(getenv("DDL_WGRAD_BIG_NST")) : 3;  // tuning knob
         p.tiles_k = K / 256;

@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
             float g = bf2f(d[e]), yf = bf2f(yv[e]);
             if (MASK == 1) g = bf2f(zv[e]) > 0.f ? g : 0.f;
             if (MASK == 2) g = bn_affine(yf, sc[e], sh[e]) > 0.f ? g : 0.f;
-            o[e] = f2bf(ca[e] * g + cb[e] * yf + c0[e]);
+            o[e] = f2bf(bn_bwd_affine(g, yf, ca[e], cb[e], c0[e]));
             if (WRITE_G) go[e] = f2bf(g);
         }
         st8<NT>(dy + (i << 3), o);

@@ -188,7 +188,7 @@ def _is_stem(w, stride, padding):
 
 
 def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho, Wo, n_valid=None,
-                accumulate=False, stream=None, workspace=None, x_fcoef=None):
+                accumulate=False, stream=None, workspace=None, x_fcoef=None, dy_y=None, dy_coef=None):
     """Backward-weights: split-K partials then ordered reduction into a tensor shaped like
     ``w_like`` (memory [K][R][S][C]).  ``stream`` (raw handle) / ``workspace`` (callable: bytes ->
     device address valid on that stream): the side-stream path, which neither switches torch's
@@ -202,7 +202,7 @@ def _wgrad_into(dy, x_ptr_tensor, geom, w_like, Kc, R, S, stride, pad, pad_w, Ho
     else:
         partial = workspace(4 * splits * slab)
     K.conv_wgrad(dy, x_ptr_tensor, geom, partial, Kc, R, S, stride, pad, pad_w, Ho, Wo, splits,
-                 stream=stream, x_fcoef=x_fcoef)
+                 stream=stream, x_fcoef=x_fcoef, dy_y=dy_y, dy_coef=dy_coef)
     n = slab if n_valid is None else n_valid
     K.splitk_reduce(partial, w_like, n, splits, slab, accumulate, stream=stream)
     return w_like
@@ -293,6 +293,31 @@ def _rows_ok(x, w, stride, padding):
 _ROWS_BN_IN = int(_os_rows.environ.get("DDL_CONV_ROWS_BN_IN", "2"))
 
 
+# BatchNorm-backward APPLY of a 3x3 unit inside the two row-streaming kernels that consume its result (the conv's
+# backward-data and weight-gradient kernels): dy = ca*g + cb*y + cc is formed on the rows they stage in LDS and the
+# materialised dy - a read of two tensors and a write of one on the dependent chain - never exists.  Bit-identical,
+# one tensor pass of eight less, the dependent chain 56 us per block shorter - and the step is SLOWER with the
+# weight-gradient stream running (16.64 -> 16.72 ms; ResNet-34 9.53 -> 9.58): the two row-streaming kernels own a
+# whole CU each (LDS) and take turns, the separate apply pass rode along with either for free, and the backward-data
+# kernel with a third input ring takes 105 instead of 78 us in the step.  Without the side stream the folded form
+# wins (18.80 -> 18.72 ms).  Hence OFF by default; DDL_CONV_ROWS_BN_BWD=1 switches it on
+# (profiles/r3_notes.md section 20).
+_ROWS_BN_BWD = int(_os_rows.environ.get("DDL_CONV_ROWS_BN_BWD", "0"))
+
+
+def _rows_bn_bwd_ok(g, w, stride, padding, inp, y_prev):
+    """Both consumers of this unit's BatchNorm-backward output are row-streaming kernels that can form it
+    themselves: ``g`` the (masked) gradient w.r.t. the BatchNorm's output, ``w`` the unit's conv, ``inp`` that
+    conv's input (or the raw tensor it is derived from), ``y_prev`` the tensor behind the backward-data epilogue."""
+    if not _ROWS_BN_BWD or _WT_KRSC or w.dim() != 4:
+        return False
+    Kc, C, R, S = w.shape
+    B, _, H, W = g.shape
+    return Kc == 64 and C == 64 and W == 56 and _rows_ok(g, w, stride, padding) and \
+        K.conv_wgrad_rows_ok(Kc, C, R, S, H, W, stride, B) and tuple(inp.shape) == tuple(g.shape) and \
+        inp.stride() == g.stride() and y_prev.stride() == g.stride() and tuple(y_prev.shape) == tuple(g.shape)
+
+
 def _rows_bn_in_ok(x, w, stride, padding, w_next, stride_next, pad_next):
     """Unit (x, w) is a conv whose BatchNorm + ReLU output only feeds the next conv (w_next), and that conv is
     served by the row-streaming kernel on this unit's output shape."""
@@ -365,10 +390,12 @@ def _conv_dgrad(dy, w, x_shape, stride, padding, addend=None, addend_sub2=False,
     return (dx, partial) if bn_y2 is None else (dx, partial, partial2)
 
 
-def _conv_dgrad_bn(dy, w, x_shape, stride, padding, y_prev, fcoef_prev):
+def _conv_dgrad_bn(dy, w, x_shape, stride, padding, y_prev, fcoef_prev, dy_y=None, dy_coef=None):
     """Backward-data whose output is the gradient of ``relu(bn(y_prev))``: the kernel stores the
     ReLU-masked gradient g and the per-tile partials of sum g / sum g*y_prev, i.e. the reduce
-    pass of that BatchNorm's backward (K8a) rides in the epilogue.  Returns (g, partial)."""
+    pass of that BatchNorm's backward (K8a) rides in the epilogue.  Returns (g, partial).
+    ``dy_y`` + ``dy_coef`` (only where :func:`_rows_bn_bwd_ok`): ``dy`` is the gradient w.r.t. the output of the
+    BatchNorm behind this conv and the kernel forms ca*dy + cb*dy_y + cc itself."""
     B, C, H, W = x_shape
     _, _, R, S = w.shape
     wt, wrows = _dgrad_w(w)
@@ -376,8 +403,10 @@ def _conv_dgrad_bn(dy, w, x_shape, stride, padding, y_prev, fcoef_prev):
     if wrows == 0 and w.shape[0] == C and _rows_ok(dy, w, stride, padding) and \
             y_prev.stride() == g.stride():
         partial = torch.empty((B, 2, C), dtype=torch.float32, device=dy.device)   # one row per image
-        K.conv_rows3x3(dy, wt, g, stats=partial, ep_y=y_prev, ep_fcoef=fcoef_prev)
+        K.conv_rows3x3(dy, wt, g, stats=partial, ep_y=y_prev, ep_fcoef=fcoef_prev, dy_y=dy_y, dy_coef=dy_coef)
         return g, partial
+    if dy_y is not None:
+        raise K.KernelError("conv_dgrad_bn: only the row-streaming kernel forms its input gradient")
     T = K.conv_tiles_m_bwd(B * H * W, H, W, stride, 1)
     partial = torch.empty((T, 2, C), dtype=torch.float32, device=dy.device)
     K.conv_igemm(dy, _geom(dy), wt, g, C, R, S, 1, R - 1 - padding, S - 1 - padding, stride, H, W,
@@ -406,7 +435,7 @@ def _side_prewait(device):
     return True
 
 
-def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None):
+def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None, dy_y=None, dy_coef=None):
     """dw for ``w``: written into ``w.grad`` when that is a live arena view (returns None and
     notifies the listeners), otherwise returned as a new tensor.
 
@@ -420,7 +449,7 @@ def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None):
         side = _side_stream(dy.device) if (_SIDE["on"] and Ho * Wo < _SIDE_MAX_HW) else None
         if side is None:
             _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                        accumulate=True, x_fcoef=x_fcoef)
+                        accumulate=True, x_fcoef=x_fcoef, dy_y=dy_y, dy_coef=dy_coef)
         else:
             # raw event + raw stream handle: no torch stream context, no torch Event objects and a
             # persistent partial-sum workspace (side-stream kernels run in order, one buffer
@@ -430,12 +459,13 @@ def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None):
                 if not prewaited:
                     K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
                 _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                            accumulate=True, stream=raw, workspace=_side_workspace, x_fcoef=x_fcoef)
+                            accumulate=True, stream=raw, workspace=_side_workspace, x_fcoef=x_fcoef,
+                            dy_y=dy_y, dy_coef=dy_coef)
             else:  # torch's own stream switch and events (DDL_SIDE_LEAN=0)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     _wgrad_into(dy, x, _geom(x), w.grad, Kc, R, S, stride, padding, padding, Ho, Wo,
-                                accumulate=True, x_fcoef=x_fcoef)
+                                accumulate=True, x_fcoef=x_fcoef, dy_y=dy_y, dy_coef=dy_coef)
             # The side stream reads dy and x after this function returns.  They are kept alive
             # until the join at the end of backward instead of `record_stream`: blocks with a
             # recorded stream are withheld from reuse until that stream has passed an event, and
@@ -447,14 +477,17 @@ def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None):
             # stream's reads.
             _side_mark_used()
             if _SIDE["join_queued"]:
-                _SIDE["keep"].append((dy, x))
+                _SIDE["keep"].append((dy, x, dy_y, dy_coef))
             else:  # raw call outside a backward pass: nobody is known to join, let the allocator track it
                 dy.record_stream(side)
                 x.record_stream(side)
+                for t in (dy_y, dy_coef):
+                    if t is not None:
+                        t.record_stream(side)
         _notify(w)
         return None
     return _wgrad_into(dy, x, _geom(x), torch.empty_like(w), Kc, R, S, stride, padding, padding,
-                       Ho, Wo, x_fcoef=x_fcoef)
+                       Ho, Wo, x_fcoef=x_fcoef, dy_y=dy_y, dy_coef=dy_coef)
 
 
 # ---- second stream for weight gradients --------------------------------------------------------
@@ -1457,6 +1490,22 @@ class ResidualBlockFn(Function):
                 if wstate is None:
                     wstate = _bn3_linear_wgrad_start(g_short, inp, w, prewaited=pre, pre=getattr(ctx, "lin_pre", None))
                 dw = _bn3_linear_wgrad_finish(wstate, coef_t, cs[i], coef_late=bool(early))
+                put(i, dw, dg, db)
+                _flush_notifications()
+                continue
+            if i > 0 and mask == 0 and fused is not None and _FUSE_BN_REDUCE["on"] and \
+                    _rows_bn_bwd_ok(dz, w, strides[i], pads[i], inp, ys[i - 1]):
+                # the apply pass of this unit's BatchNorm backward happens inside the two kernels that read its
+                # result: only the coefficients are computed here
+                coef_t, dg, db = _unit_coef(dz, ys[i], gam, bet, cs[i], fused)
+                if last:
+                    g_short = dz
+                pre = _side_prewait(dz.device)
+                g_in = dz
+                dz, fused = _conv_dgrad_bn(g_in, w, inp.shape, strides[i], pads[i], ys[i - 1],
+                                           cs[i - 1].data_ptr() + 8 * inp.shape[1], dy_y=ys[i], dy_coef=coef_t)
+                dw = _conv_wgrad(g_in, inp, w, strides[i], pads[i], prewaited=pre, x_fcoef=inp_fcoef,
+                                 dy_y=ys[i], dy_coef=coef_t)
                 put(i, dw, dg, db)
                 _flush_notifications()
                 continue

@@ -331,18 +331,21 @@ def conv_rows3x3_ok(C, N, R, S, stride, pad, H, W):
     return bool(lib().ddl_conv_rows3x3_ok(_i32(C), _i32(N), _i32(R), _i32(S), _i32(stride), _i32(pad), _i32(H), _i32(W)))
 
 
-def conv_rows3x3(x, w, y, stats=None, ep_y=None, ep_fcoef=None, stream=None, in_fcoef=None, z_out=None):
+def conv_rows3x3(x, w, y, stats=None, ep_y=None, ep_fcoef=None, stream=None, in_fcoef=None, z_out=None,
+                 dy_y=None, dy_coef=None):
     """y = conv3x3(x, w), stride 1, pad 1, for dense NHWC [B, 64, H, 56] tensors and a [64][3][3][64] filter.
     ``stats`` ([B][2][64] fp32, tensor or raw address): per-image sum y | sum y^2; with ``ep_y`` + ``ep_fcoef``
     (backward-data of a layer behind BatchNorm + ReLU) y is the masked gradient g and the table holds
     sum g | sum g*ep_y.  ``in_fcoef`` ([2][64] fp32 scale | shift, tensor or raw address) + ``z_out`` (forward):
     ``x`` is the RAW input of a BatchNorm + ReLU in front of this conv; the kernel applies them to the rows it has
-    staged, convolves the result and also writes it to ``z_out``."""
+    staged, convolves the result and also writes it to ``z_out``.  ``dy_y`` + ``dy_coef`` ([3][64] fp32 ca | cb | cc,
+    tensor or raw address; backward-data form only): ``x`` is the gradient with respect to a BatchNorm's output and
+    ``dy_y`` that BatchNorm's input - the kernel convolves ca*x + cb*dy_y + cc, the backward apply pass folded in."""
     B, C, H, W = x.shape
     N = y.shape[1]
     if tuple(y.shape) != (B, N, H, W) or not conv_rows3x3_ok(C, N, 3, 3, 1, 1, H, W):
         raise KernelError("conv_rows3x3: unsupported shape %s -> %s" % (tuple(x.shape), tuple(y.shape)))
-    for t in (x, y, ep_y):
+    for t in (x, y, ep_y, dy_y):
         if t is not None and (tuple(t.shape) != (B, C, H, W) or t.stride() != (H * W * C, 1, W * C, C)):
             raise KernelError("conv_rows3x3: tensors must be dense channels_last [B, 64, H, 56]")
     if w.numel() != N * 9 * C:
@@ -353,9 +356,9 @@ def conv_rows3x3(x, w, y, stats=None, ep_y=None, ep_fcoef=None, stream=None, in_
         LAUNCH_LOG.append(("conv_rows", B, H, W, C, H, W, N, 3, 3, 1, 1, B * H * W, int(ep_y is not None)))
     if z_out is not None and (tuple(z_out.shape) != (B, C, H, W) or z_out.stride() != x.stride()):
         raise KernelError("conv_rows3x3: z_out must look like the input")
-    f = _fn("ddl_conv_rows3x3", "pppppp pp iiiii p")
+    f = _fn("ddl_conv_rows3x3", "pppppp pp pp iiiii p")
     check(f(x.data_ptr(), w.data_ptr(), y.data_ptr(), _p(stats), _p(ep_y), _p(ep_fcoef), _p(in_fcoef), _p(z_out),
-            B, H, W, C, N, _raw_stream() if stream is None else stream), "conv_rows3x3")
+            _p(dy_y), _p(dy_coef), B, H, W, C, N, _raw_stream() if stream is None else stream), "conv_rows3x3")
 
 
 @functools.lru_cache(maxsize=None)
@@ -386,20 +389,25 @@ def conv_wgrad_rows_ok(K, C, R, S, Hout, Wout, stride, B):
 
 
 def conv_wgrad(dy, x_ptr_tensor, geom, partial, K, R, S, stride, pad, pad_w, Hout, Wout, splits,
-               stream=None, colsum=None, x_fcoef=None):
+               stream=None, colsum=None, x_fcoef=None, dy_y=None, dy_coef=None):
     """``partial``: tensor or raw address; ``stream``: raw HIP stream (default: current).  ``colsum`` (raw address
     or tensor, plain GEMMs with :func:`conv_wgrad_colsum_ok`): receives [splits][2][C] fp32 column sums of x per
     split, both rows alike - a statistics-table layout that :func:`bn_colsum_fold` sums.  ``x_fcoef`` ([2][C] fp32
     scale | shift, raw address or tensor; only where :func:`conv_wgrad_rows_ok` and C = 64 on 56-pixel rows): ``x``
-    is the RAW input of a BatchNorm + ReLU whose output is the conv's real input - applied on the staged rows."""
+    is the RAW input of a BatchNorm + ReLU whose output is the conv's real input - applied on the staged rows.
+    ``dy_y`` (tensor like ``dy``) + ``dy_coef`` ([3][K] fp32 ca | cb | cc; same kernel, K = 64): ``dy`` is the gradient
+    with respect to a BatchNorm's output, ``dy_y`` that BatchNorm's input: the product uses ca*dy + cb*dy_y + cc."""
     B, Hin, Win, C, sb, sh, sw, xn = geom
     if _PROBE_SKIP_WGRAD == "all" or (_PROBE_SKIP_WGRAD == "late" and Hout <= 14) or (_PROBE_SKIP_WGRAD == "early" and Hout > 14):
         return   # timing probe only (gradients are garbage): what the step costs without these launches
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append(("conv_wgrad", B, Hin, Win, C, Hout, Wout, K, R, S, stride, 1, dy.numel() // K, splits))
-    f = _fn("ddl_conv_wgrad_ex2", "ppp qq iiii qqq iiiiiiiii pp p")
+    if dy_y is not None and (dy_y.shape != dy.shape or dy_y.stride() != dy.stride()):
+        raise KernelError("conv_wgrad: dy_y must look like dy")
+    f = _fn("ddl_conv_wgrad_ex3", "ppp qq iiii qqq iiiiiiiii pp pp p")
     check(f(dy.data_ptr(), x_ptr_tensor.data_ptr(), _p(partial), dy.numel(), xn, B, Hin, Win,
             C, sb, sh, sw, Hout, Wout, K, R, S, stride, pad, pad_w, splits, _p(colsum), _p(x_fcoef),
+            _p(dy_y), _p(dy_coef),
             _raw_stream() if stream is None else stream), "conv_wgrad")
 
 

@@ -1205,3 +1205,115 @@ def test_conv_rows3x3_applies_the_batchnorm_in_front_of_it():
         K.conv_wgrad(dy, z_ref, hip._geom(z_ref), s_ref, 64, 3, 3, 1, 1, 1, H, 56, splits)
         K.conv_wgrad(dy, y0, hip._geom(y0), s_xf, 64, 3, 3, 1, 1, 1, H, 56, splits, x_fcoef=fco)
         assert torch.equal(s_xf, s_ref)
+
+
+def test_row_streaming_kernels_form_the_batchnorm_backward_gradient_themselves():
+    """dy = ca*g + cb*y + cc (a BatchNorm's backward apply) formed inside the row-streaming backward-data and
+    weight-gradient kernels on the rows they stage, against the separate apply pass followed by the plain kernels:
+    bit-identical (same operation order, same bf16 rounding of dy)."""
+    from distributeddeeplearning_amd.ops import hip_ops as hip
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    K.require()
+    B, H = 3, 56
+    if not (K.conv_rows3x3_ok(64, 64, 3, 3, 1, 1, H, 56) and K.conv_wgrad_rows_ok(64, 64, 3, 3, H, 56, 1, B)):
+        pytest.skip("row-streaming kernels switched off")
+    M = B * H * 56
+    g2 = rand_nhwc(B, 64, H, 56, seed=41)
+    y2 = rand_nhwc(B, 64, H, 56, seed=42)
+    y_prev = rand_nhwc(B, 64, H, 56, seed=43)
+    x_raw = rand_nhwc(B, 64, H, 56, seed=44)
+    wt = (torch.randn((64, 64, 3, 3), device=DEV) / 24.0).to(BF).contiguous(memory_format=CL)
+    coef = torch.stack([torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.2,
+                        torch.randn(64, device=DEV) * 0.1]).contiguous()
+    fco = torch.stack([torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.3]).contiguous()
+    dy = torch.empty_like(g2)
+    K.bn_bwd_apply(g2, y2, None, None, coef.data_ptr(), dy, None, M, 64, 0)
+    # backward-data: masked gradient and the partial sums of the BatchNorm in front
+    g_ref = torch.empty_like(g2)
+    p_ref = torch.empty((B, 2, 64), device=DEV)
+    K.conv_rows3x3(dy, wt, g_ref, stats=p_ref, ep_y=y_prev, ep_fcoef=fco)
+    g = torch.full_like(g2, float("nan"))
+    p = torch.full((B, 2, 64), float("nan"), device=DEV)
+    K.conv_rows3x3(g2, wt, g, stats=p, ep_y=y_prev, ep_fcoef=fco, dy_y=y2, dy_coef=coef)
+    assert torch.equal(g, g_ref)
+    assert torch.equal(p, p_ref)
+    # weight gradient, with a plain input and with an input that is transformed as well
+    splits = K.conv_wgrad_splits(M, 64, 64, 3, 3, H, 56, 1, B)
+    z = torch.empty_like(x_raw)
+    K.bn_apply_fwd(x_raw, fco[0], fco[1], None, z, M, 64, True)
+    s_ref = torch.empty((splits, 64 * 9 * 64), device=DEV)
+    K.conv_wgrad(dy, z, hip._geom(z), s_ref, 64, 3, 3, 1, 1, 1, H, 56, splits)
+    s_a = torch.full_like(s_ref, float("nan"))
+    K.conv_wgrad(g2, z, hip._geom(z), s_a, 64, 3, 3, 1, 1, 1, H, 56, splits, dy_y=y2, dy_coef=coef)
+    assert torch.equal(s_a, s_ref)
+    s_b = torch.full_like(s_ref, float("nan"))
+    K.conv_wgrad(g2, x_raw, hip._geom(x_raw), s_b, 64, 3, 3, 1, 1, 1, H, 56, splits, x_fcoef=fco, dy_y=y2, dy_coef=coef)
+    assert torch.equal(s_b, s_ref)
+    # shapes the kernel does not serve refuse the extra operands instead of ignoring them
+    small = rand_nhwc(2, 64, 28, 28, seed=45)
+    with pytest.raises(K.KernelError):
+        sp = K.conv_wgrad_splits(2 * 28 * 28, 64, 64, 3, 3, 28, 28, 1, 2)
+        K.conv_wgrad(small, small, hip._geom(small), torch.empty((sp, 64 * 9 * 64), device=DEV), 64, 3, 3, 1, 1, 1,
+                     28, 28, sp, dy_y=small, dy_coef=coef)
+
+
+@pytest.mark.parametrize("kind", ["bottleneck", "basic"])
+def test_blocks_with_the_backward_apply_folded_into_the_row_kernels_are_bit_identical(kind):
+    """A chain of stage-1 blocks with DDL_CONV_ROWS_BN_BWD on and off: every gradient is bit-identical, and the
+    folded path is really taken (once per block whose incoming gradient is pre-masked by the next block)."""
+    from distributeddeeplearning_amd.models.resnet import BasicBlock, Bottleneck, _block_spec
+    from distributeddeeplearning_amd.ops import functional as ops
+
+    hip = _hip()
+
+    def make():
+        torch.manual_seed(11)
+        if kind == "bottleneck":
+            ms = [Bottleneck(64, 64, 1, True, False), Bottleneck(256, 64, 1, False, False),
+                  Bottleneck(256, 64, 1, False, False)]
+        else:
+            ms = [BasicBlock(64, 64, 1, False, False), BasicBlock(64, 64, 1, False, False),
+                  BasicBlock(64, 64, 1, False, False)]
+        for m in ms:
+            m.to(DEV).train()
+            for mod in m.modules():
+                if hasattr(mod, "kernel"):
+                    mod.weight.data = mod.weight.data.to(BF).contiguous(memory_format=CL)
+        return ms
+
+    x0 = torch.relu(rand_nhwc(4, 64, 56, 56, seed=71))
+    gout = rand_nhwc(4, 256 if kind == "bottleneck" else 64, 56, 56, seed=72)
+    used = {"n": 0}
+    real = hip._unit_coef
+
+    def counting(*a, **k):
+        used["n"] += 1
+        return real(*a, **k)
+
+    def run(on):
+        hip.reset_caches()
+        ms = make()
+        x = x0.detach().clone().requires_grad_(True)
+        saved = hip._ROWS_BN_BWD
+        hip._ROWS_BN_BWD = on
+        hip._unit_coef = counting
+        try:
+            out = ops.residual_chain(x, [_block_spec(m.pairs(), m.downsample) for m in ms], True, 0.1, 1e-5)
+            out.backward(gout)
+            torch.cuda.synchronize()
+        finally:
+            hip._ROWS_BN_BWD = saved
+            hip._unit_coef = real
+        names = [n for m in ms for n, _ in m.named_parameters()]
+        return x.grad, names, [p.grad.clone() for m in ms for p in m.parameters()]
+
+    used["n"] = 0
+    dx_b, names, g_b = run(0)
+    base = used["n"]                   # (the linearity path of the bottlenecks uses the same helper)
+    used["n"] = 0
+    dx_a, _, g_a = run(1)
+    assert used["n"] - base == (3 if kind == "bottleneck" else 2), (used, base)
+    assert torch.equal(dx_a, dx_b)
+    for n, a, b in zip(names, g_a, g_b):
+        assert torch.equal(a, b), n
