@@ -712,6 +712,11 @@ int launch_cfg(const IGemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+// the 256 x 256 / 8-wave plain-GEMM kernel of the wide 1x1 layers (gemm256.hip)
+extern "C" int ddl_gemm256_ok(long long M, int N, int K);
+extern "C" int ddl_gemm256_fwd(const void* x, const void* w, void* y, void* stats, long long M, int N, int K,
+                               long long x_numel, int stat_rows, hipStream_t stream);
+
 static unsigned long long* g_conv_dbg = nullptr;
 // probe builds (-DDDL_CONV_PROBES): every launch writes [block][8] cycle stamps of wave 0 here
 extern "C" void ddl_conv_set_debug_buffer(void* p) { g_conv_dbg = (unsigned long long*)p; }
@@ -813,6 +818,10 @@ extern "C" int ddl_conv_igemm_ex4(const void* x, const void* w, void* y, const v
                 xs_h == (long long)Win * xs_w && xs_b == (long long)Hin * xs_h) ? 1 : 0;
     if (addend_sub2 && (!addend || (Hout & 1) || (Wout & 1))) return DDL_EINVAL;
     p.addend_sub2 = addend_sub2;
+    // wide plain GEMMs without a fused backward epilogue (forward 1x1 convs of stages 3-4, with or without
+    // statistics): the 8-wave ring kernel
+    if (p.simple && xs_w == C && !addend && !ep_y && !has_mask && !x2 && !wt && !probe && !g_conv_dbg && ddl_gemm256_ok(M, N, C))
+        return ddl_gemm256_fwd(x, w, y, stats, M, N, C, x_numel, (int)((M + 127) / 128), stream);
     p.tiles_m = (int)((M + 127) / 128);
     p.stat_rows = p.tiles_m;
     p.parity = 0; p.tiles_per_class = 0; p.Mc = 0;

@@ -325,6 +325,26 @@ def conv_tiles_m(M):
 
 
 @functools.lru_cache(maxsize=None)
+def gemm256_ok(M, N, K):
+    """True when a plain-GEMM conv launch ([M][K] x [N][K]^T, no fused backward epilogue) is served by the
+    256 x 256 / 8-wave kernel (csrc/kernels/gemm256.hip); the dispatch itself happens inside ``conv_igemm``."""
+    return bool(lib().ddl_gemm256_ok(_i64(M), _i32(N), _i32(K)))
+
+
+def gemm256_fwd(x2d, w2d, y2d, stats=None, stream=None):
+    """y2d [M][N] = x2d [M][K] @ w2d [N][K]^T on the 256 x 256 / 8-wave kernel, whatever the dispatch policy says
+    (N % 256 == 0, K % 32 == 0); ``stats`` ([ceil(M / 128)][2][N] fp32): sum | sum of squares of the rounded outputs."""
+    M, Kd = x2d.shape
+    N = w2d.shape[0]
+    if tuple(y2d.shape) != (M, N) or w2d.shape[1] != Kd or not (x2d.is_contiguous() and w2d.is_contiguous() and y2d.is_contiguous()):
+        raise KernelError("gemm256_fwd: dense [M][K], [N][K] and [M][N] operands expected")
+    rows = 0 if stats is None else stats.shape[0]
+    f = _fn("ddl_gemm256_fwd", "pppp qii qi p")
+    check(f(x2d.data_ptr(), w2d.data_ptr(), y2d.data_ptr(), _p(stats), M, N, Kd, x2d.numel(), rows,
+            _raw_stream() if stream is None else stream), "gemm256_fwd")
+
+
+@functools.lru_cache(maxsize=None)
 def conv_rows3x3_ok(C, N, R, S, stride, pad, H, W):
     """True when the row-streaming 3x3 kernel (csrc/kernels/conv_rows.hip) serves this layer, forward and
     backward-data; its statistics / BatchNorm-backward partial table has ONE row per image."""

@@ -60,6 +60,8 @@ CONV_CASES = [
     (96, 1024, 23, 23, 256, 1, 1, 0), # 256x128 tile, 1x1 (fwd); its dgrad (N = 1024, C = 256) stays on 128x128
     (33, 64, 56, 56, 256, 1, 1, 0),   # weight gradient over > 100 000 rows: interleaved reduction ranges, ragged last group
     (33, 256, 56, 56, 64, 1, 1, 0),   # the same with the wide side as the input
+    (64, 256, 14, 14, 1024, 1, 1, 0), # 256x256 / 8-wave plain-GEMM kernel (gemm256.hip): 196 whole tiles, short reduction
+    (65, 1024, 14, 14, 1024, 1, 1, 0),  # ... long reduction, ragged last tile (68 rows in its last 128-row statistics row)
 ]
 
 
@@ -1317,3 +1319,40 @@ def test_blocks_with_the_backward_apply_folded_into_the_row_kernels_are_bit_iden
     assert torch.equal(dx_a, dx_b)
     for n, a, b in zip(names, g_a, g_b):
         assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("M,N,Kd", [(64 * 196, 1024, 256), (65 * 196, 1024, 1024), (300, 256, 64)])
+def test_gemm256_kernel_against_the_tile_kernel_and_fp32(M, N, Kd):
+    """gemm256.hip (256 x 256 tile, 8 waves, LDS-DMA ring; opt-in for the wide 1x1 layers, DDL_GEMM256=1) called
+    directly: outputs bit-identical to the 128 x 128 tile kernel (same reduction order), statistics table equal to
+    rounding, both within bf16 accuracy of fp32; ragged last tile and last statistics row."""
+    from distributeddeeplearning_amd.ops import hip_ops as hip
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    K.require()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((M, Kd), generator=g, device=DEV).to(BF)
+    w = (torch.randn((N, Kd), generator=g, device=DEV) / math.sqrt(Kd)).to(BF)
+    rows = (M + 127) // 128
+    y = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+    st = torch.full((rows, 2, N), float("nan"), device=DEV)
+    K.gemm256_fwd(x, w, y, st)
+    ref = x.float() @ w.float().t()
+    assert relerr(y, ref) < 1.5e-2 and rms_relerr(y, ref) < 4e-3
+    yf = y.float()
+    pad = rows * 128 - M
+    yp = torch.cat([yf, torch.zeros((pad, N), device=DEV)]) if pad else yf
+    assert torch.allclose(st[:, 0, :], yp.view(rows, 128, N).sum(1), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(st[:, 1, :], (yp * yp).view(rows, 128, N).sum(1), rtol=1e-3, atol=1e-2)
+    # the tile kernel on the same operands (as a 1x1 conv over an [M, Kd, 1, 1] image)
+    x4 = x.view(M, Kd, 1, 1).contiguous(memory_format=CL)
+    y_t = torch.empty((M, N), dtype=BF, device=DEV)
+    st_t = torch.empty((K.conv_tiles_m(M), 2, N), device=DEV)
+    K.conv_igemm(x4, hip._geom(x4), w, y_t, N, 1, 1, 1, 0, 0, 1, 1, 1, stats=st_t)
+    assert torch.equal(y, y_t)
+    assert torch.allclose(st, st_t, rtol=1e-4, atol=1e-3)
+    y2 = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+    K.gemm256_fwd(x, w, y2)          # without statistics
+    assert torch.equal(y2, y)
+    with pytest.raises(K.KernelError):
+        K.gemm256_fwd(x, w[:128].contiguous(), torch.empty((M, 128), dtype=BF, device=DEV))   # N % 256 != 0
