@@ -841,7 +841,8 @@ extern "C" int ddl_conv_igemm_ex4(const void* x, const void* w, void* y, const v
     // BK = 64 (one barrier per 64 reduction elements, 64 KB of LDS per workgroup): every 3x3 (the
     // parity-ordered stride-2 backward only from 512 channels), 1x1 from 2048 channels, and the
     // narrow-output 1x1 (N <= 64) from 256
-    bool deep = (R * S == 1) ? (C >= 2048 || (N <= 64 && C >= 256)) : (p.parity ? C >= 512 : true);
+    static const int deep_min_c = getenv("DDL_CONV_DEEP_MIN_C") ? atoi(getenv("DDL_CONV_DEEP_MIN_C")) : 2048;  // tuning knob
+    bool deep = (R * S == 1) ? (C >= deep_min_c || (N <= 64 && C >= 256)) : (p.parity ? C >= 512 : true);
     // 256x128 block tile, BK = 32 (wave tile 128x64: a quarter fewer LDS and L2->LDS bytes per FLOP)
     // for exactly two N tiles sharing the A panel, a long reduction and enough tiles to fill the
     // chip: c4 3x3 256->256 @14 fwd 71 (BK=64) -> 65 us, dgrad 68 -> 62 us.  With more N tiles, short
