@@ -435,14 +435,16 @@ def _side_prewait(device):
     return True
 
 
-def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None, dy_y=None, dy_coef=None):
+def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None, dy_y=None, dy_coef=None, keep=()):
     """dw for ``w``: written into ``w.grad`` when that is a live arena view (returns None and
     notifies the listeners), otherwise returned as a new tensor.
 
     In direct mode the kernel pair (split-K partials + ordered reduce) runs on a second HIP
     stream: weight gradients are off the critical path of backward (nothing downstream in the
     backward pass reads them), so they fill the bubbles the dependent chain dgrad -> BN finalize
-    -> BN apply leaves on the main stream."""
+    -> BN apply leaves on the main stream.  ``keep``: tensors behind raw addresses among the arguments
+    (``x_fcoef`` points into a SAVED coefficient block) - the side stream reads them after the autograd node
+    has returned and released its saved tensors, so they are held until the join like ``dy`` and ``x``."""
     Kc, _, R, S = w.shape
     Ho, Wo = dy.shape[2], dy.shape[3]
     if _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]:
@@ -477,12 +479,12 @@ def _conv_wgrad(dy, x, w, stride, padding, prewaited=False, x_fcoef=None, dy_y=N
             # stream's reads.
             _side_mark_used()
             if _SIDE["join_queued"]:
-                _SIDE["keep"].append((dy, x, dy_y, dy_coef))
+                _SIDE["keep"].append((dy, x, dy_y, dy_coef) + tuple(keep))
             else:  # raw call outside a backward pass: nobody is known to join, let the allocator track it
                 dy.record_stream(side)
                 x.record_stream(side)
-                for t in (dy_y, dy_coef):
-                    if t is not None:
+                for t in (dy_y, dy_coef) + tuple(keep):
+                    if torch.is_tensor(t):
                         t.record_stream(side)
         _notify(w)
         return None
@@ -1505,7 +1507,7 @@ class ResidualBlockFn(Function):
                 dz, fused = _conv_dgrad_bn(g_in, w, inp.shape, strides[i], pads[i], ys[i - 1],
                                            cs[i - 1].data_ptr() + 8 * inp.shape[1], dy_y=ys[i], dy_coef=coef_t)
                 dw = _conv_wgrad(g_in, inp, w, strides[i], pads[i], prewaited=pre, x_fcoef=inp_fcoef,
-                                 dy_y=ys[i], dy_coef=coef_t)
+                                 dy_y=ys[i], dy_coef=coef_t, keep=(cs[i - 1],))
                 put(i, dw, dg, db)
                 _flush_notifications()
                 continue
@@ -1523,7 +1525,8 @@ class ResidualBlockFn(Function):
                                                cs[i - 1].data_ptr() + 8 * inp.shape[1])
                 else:
                     dz, fused = _conv_dgrad(dy, w, inp.shape, strides[i], pads[i]), None
-                dw = _conv_wgrad(dy, inp, w, strides[i], pads[i], prewaited=pre, x_fcoef=inp_fcoef)
+                dw = _conv_wgrad(dy, inp, w, strides[i], pads[i], prewaited=pre, x_fcoef=inp_fcoef,
+                                 keep=(cs[i - 1],) if inp_fcoef is not None else ())
                 put(i, dw, dg, db)
                 _flush_notifications()  # the chain's next kernel is queued: now talk to the exchange
             else:

@@ -1356,3 +1356,46 @@ def test_gemm256_kernel_against_the_tile_kernel_and_fp32(M, N, Kd):
     assert torch.equal(y2, y)
     with pytest.raises(K.KernelError):
         K.gemm256_fwd(x, w[:128].contiguous(), torch.empty((M, 128), dtype=BF, device=DEV))   # N % 256 != 0
+
+
+def test_raw_addresses_handed_to_the_weight_gradient_stream_are_kept_alive():
+    """The weight-gradient stream reads its operands after the autograd node has returned and released its saved
+    tensors.  Every raw address among them must therefore come with its owner in ``keep`` (found as a 1-in-1000-steps
+    run-to-run difference of ResNet-101: the saved BatchNorm coefficients behind ``x_fcoef`` were recycled by the main
+    stream before the queued weight gradient had read them; profiles/r3_notes.md section 22).  One real training
+    step of ResNet-18 (gradient arenas, side stream) with a spy on the launcher."""
+    import distributeddeeplearning_amd.torch as hvd
+    from distributeddeeplearning_amd.models import resnet18
+    from distributeddeeplearning_amd.ops import functional as ops
+    from distributeddeeplearning_amd.optim import FusedSGD
+
+    hip = _hip()
+    if hip._ROWS_BN_IN != 2:
+        pytest.skip("the activated tensor is materialised: no raw coefficient address reaches the weight gradient")
+    hvd.init()
+    torch.manual_seed(13)
+    model = resnet18(num_classes=64).to_compute(torch.device(DEV), BF).train()
+    opt = hvd.DistributedOptimizer(FusedSGD(model.named_parameters(), lr=0.01, momentum=0.9),
+                                   named_parameters=model.named_parameters())
+    seen = []
+    real = hip._conv_wgrad
+
+    def spy(dy, x, w, stride, padding, prewaited=False, x_fcoef=None, dy_y=None, dy_coef=None, keep=()):
+        if x_fcoef is not None:
+            addr = x_fcoef if isinstance(x_fcoef, int) else x_fcoef.data_ptr()
+            seen.append(any(torch.is_tensor(t) and t.data_ptr() <= addr < t.data_ptr() + t.numel() * t.element_size()
+                            for t in keep))
+        return real(dy, x, w, stride, padding, prewaited=prewaited, x_fcoef=x_fcoef, dy_y=dy_y, dy_coef=dy_coef, keep=keep)
+
+    hip._conv_wgrad = spy
+    try:
+        x = torch.rand((4, 3, 224, 224), device=DEV).to(BF).contiguous(memory_format=CL)
+        y = torch.randint(0, 64, (4,), device=DEV)
+        opt.zero_grad()
+        loss = ops.softmax_cross_entropy(model(x), y)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+    finally:
+        hip._conv_wgrad = real
+    assert len(seen) >= 2 and all(seen), seen     # the two stage-1 blocks of ResNet-18
