@@ -1031,8 +1031,10 @@ static bool wgrad_big(long long M, int K, int C, int R, int S) {
 static int wgrad_big_splits(long long M, int K, int C, int R, int S) {
     // In the training step fewer, longer workgroups win (each costs 256 KB of partial-sum traffic and one CU's
     // LDS): 64 / 96 / 128 / 160 / 192 / 256 workgroups -> 18.13 / 17.85 / 17.80 / 17.70 / 17.73 / 18.01 ms per step
-    // against 18.18-18.24 ms with the 128 x 128 kernel (profiles/r3_notes.md)
-    static const int target = getenv("DDL_WGRAD_BIG_TARGET") ? atoi(getenv("DDL_WGRAD_BIG_TARGET")) : 160;  // tuning knob
+    // against 18.18-18.24 ms with the 128 x 128 kernel (profiles/r3_notes.md).  Swept again on the final tree of the
+    // round (row-streaming kernels next to it): 96 / 112 / 128 / 144 / 160 -> 16.79 / 16.78 / 16.65 / 16.81 / 16.69 ms,
+    // ResNet-101 28.24 -> 28.08, ResNet-152 40.72 -> 40.54 for 160 -> 128 (not monotonic: the count is rounded per layer)
+    static const int target = getenv("DDL_WGRAD_BIG_TARGET") ? atoi(getenv("DDL_WGRAD_BIG_TARGET")) : 128;  // tuning knob
     const long long tiles = (long long)(K / 256) * ((long long)R * S * C / 256);
     long long want = (target + tiles / 2) / tiles;
     const long long max_by_m = M / 512;                    // at least 16 tiles of 32 rows per split
