@@ -164,8 +164,10 @@ extern "C" int ddl_fused_sgd(void* w, const void* g, void* v, void* lowp, long l
 }
 
 // ---------------------------------------------------------------------------------------
-// K15: LARS.  Pass 1: per-segment sum(w^2), sum(g^2) (chunked, fp32 atomics onto a zeroed
-// [2, nseg] table: a few hundred atomics per step, far below the atomic-rate regime).
+// K15: LARS.  Pass 1: per-segment sum(w^2), sum(g^2), chunked and DETERMINISTIC (no float atomics: a segment
+// that lies inside one chunk is summed by that chunk's block and stored; a segment that crosses chunk borders
+// gets one partial per chunk - a chunk has at most one segment entering from the left and one leaving to the
+// right, two slots - and a second small kernel adds a segment's partials in chunk order).
 // Pass 2: v = mu*v + lr*ratio[seg]*(g + wd*w); w -= v.
 // Segments are [seg_start[k], seg_end[k]) element ranges relative to the run base; padding
 // between segments holds zeros and is never touched.
@@ -185,7 +187,8 @@ template <bool GRAD_BF16>
 __global__ void __launch_bounds__(256) segmented_sqnorm_kernel(const float* __restrict__ w, const void* __restrict__ gv,
                                                               const long long* __restrict__ seg_start,
                                                               const long long* __restrict__ seg_end, int nseg,
-                                                              long long n, float* __restrict__ out /*[2][nseg]*/) {
+                                                              long long n, float* __restrict__ out /*[2][nseg]*/,
+                                                              float* __restrict__ part /*[chunks][2 slots][2]*/) {
     __shared__ float red[2][4];
     long long c0 = (long long)blockIdx.x * LARS_CHUNK;
     long long c1 = c0 + LARS_CHUNK < n ? c0 + LARS_CHUNK : n;
@@ -204,11 +207,33 @@ __global__ void __launch_bounds__(256) segmented_sqnorm_kernel(const float* __re
         if ((threadIdx.x & 63) == 0) { red[0][wid] = sw; red[1][wid] = sg; }
         __syncthreads();
         if (threadIdx.x == 0 && b > a) {
-            atomicAdd(out + k, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-            atomicAdd(out + nseg + k, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+            const float tw = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            const float tg = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+            if (seg_start[k] >= c0 && seg_end[k] <= c1) {            // the whole segment: final
+                out[k] = tw; out[nseg + k] = tg;
+            } else {
+                float* slot = part + ((long long)blockIdx.x * 2 + (seg_start[k] < c0 ? 0 : 1)) * 2;
+                slot[0] = tw; slot[1] = tg;
+            }
         }
         __syncthreads();
     }
+}
+
+// segments that cross chunk borders: their partials in chunk order (the first chunk's right slot, then left slots);
+// empty segments: zero
+__global__ void __launch_bounds__(256) segmented_sqnorm_join_kernel(const long long* __restrict__ seg_start,
+                                                                   const long long* __restrict__ seg_end, int nseg,
+                                                                   const float* __restrict__ part, float* __restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nseg) return;
+    const long long a = seg_start[k], b = seg_end[k];
+    if (b <= a) { out[k] = 0.f; out[nseg + k] = 0.f; return; }
+    const long long first = a / LARS_CHUNK, last = (b - 1) / LARS_CHUNK;
+    if (first == last) return;                                     // written by the chunk's block
+    float tw = part[(first * 2 + 1) * 2], tg = part[(first * 2 + 1) * 2 + 1];
+    for (long long c = first + 1; c <= last; ++c) { tw += part[(c * 2) * 2]; tg += part[(c * 2) * 2 + 1]; }
+    out[k] = tw; out[nseg + k] = tg;
 }
 
 template <bool GRAD_BF16, bool HAS_LOWP>
@@ -254,18 +279,23 @@ extern "C" int ddl_lars_trust_ratios(const void* sq, int nseg, float tc, float w
     return ddl_launch_status();
 }
 
+// floats of scratch `ddl_segmented_sqnorms` needs for a run of n elements
+extern "C" long long ddl_segmented_sqnorms_scratch(long long n) { return 4 * ((n + LARS_CHUNK - 1) / LARS_CHUNK); }
+
+// out [2][nseg] = sum w^2 | sum g^2 per segment; segments must be sorted and disjoint; `scratch`: fp32 workspace of
+// ddl_segmented_sqnorms_scratch(n) floats
 extern "C" int ddl_segmented_sqnorms(const void* w, const void* g, int grad_is_bf16, const void* seg_start,
-                                     const void* seg_end, int nseg, long long n, void* out, hipStream_t stream) {
-    if (!w || !g || !seg_start || !seg_end || !out || nseg <= 0 || n <= 0) return DDL_EINVAL;
-    if (hipMemsetAsync(out, 0, sizeof(float) * 2 * nseg, stream) != hipSuccess) return DDL_ELAUNCH;
-    if (ddl::tape::recording()) ddl::tape::push([=]() { (void)hipMemsetAsync(out, 0, sizeof(float) * 2 * nseg, stream); });
+                                     const void* seg_end, int nseg, long long n, void* out, void* scratch, hipStream_t stream) {
+    if (!w || !g || !seg_start || !seg_end || !out || !scratch || nseg <= 0 || n <= 0) return DDL_EINVAL;
     dim3 grid((unsigned)((n + LARS_CHUNK - 1) / LARS_CHUNK)), block(256);
     if (grad_is_bf16)
         DDL_KLAUNCH(segmented_sqnorm_kernel<true>, grid, block, 0, stream, (const float*)w, g,
-                           (const long long*)seg_start, (const long long*)seg_end, nseg, n, (float*)out);
+                           (const long long*)seg_start, (const long long*)seg_end, nseg, n, (float*)out, (float*)scratch);
     else
         DDL_KLAUNCH(segmented_sqnorm_kernel<false>, grid, block, 0, stream, (const float*)w, g,
-                           (const long long*)seg_start, (const long long*)seg_end, nseg, n, (float*)out);
+                           (const long long*)seg_start, (const long long*)seg_end, nseg, n, (float*)out, (float*)scratch);
+    DDL_KLAUNCH(segmented_sqnorm_join_kernel, dim3((nseg + 255) / 256), dim3(256), 0, stream, (const long long*)seg_start,
+                (const long long*)seg_end, nseg, (const float*)scratch, (float*)out);
     return ddl_launch_status();
 }
 

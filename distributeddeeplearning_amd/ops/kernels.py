@@ -191,13 +191,20 @@ def fused_sgd_(w, g, v, lowp, lr, mu, wd, nesterov, lr_scale=None) -> None:
                                  stream()), "fused_sgd")
 
 
+@functools.lru_cache(maxsize=None)
+def _sqnorm_scratch(n):
+    lib().ddl_segmented_sqnorms_scratch.restype = ctypes.c_longlong
+    return int(lib().ddl_segmented_sqnorms_scratch(_i64(n)))
+
+
 def segmented_norms(w, g, seg_offsets, seg_ends):
     """K15 pass 1: (‖w_k‖, ‖g_k‖) for every segment k of a flat run."""
     nseg = seg_ends.numel()
     out = torch.empty((2, nseg), dtype=torch.float32, device=w.device)
+    scratch = torch.empty(_sqnorm_scratch(w.numel()), dtype=torch.float32, device=w.device)
     check(lib().ddl_segmented_sqnorms(ptr(w), ptr(g), ctypes.c_int(int(g.dtype == torch.bfloat16)),
                                       ptr(seg_offsets), ptr(seg_ends), ctypes.c_int(nseg),
-                                      _i64(w.numel()), ptr(out), stream()), "segmented_sqnorms")
+                                      _i64(w.numel()), ptr(out), ptr(scratch), stream()), "segmented_sqnorms")
     out = out.sqrt_()
     return out[0], out[1]
 
@@ -206,13 +213,14 @@ def lars_trust_ratios(w, g, seg_offsets, seg_ends, trust_coefficient, wd, eps):
     """K15 passes 1 + 1b without a framework operator: squared norms per segment, then
     ``tc*|w| / (|g| + wd*|w| + eps)`` (1 where a norm is zero) - an fp32 [nseg] tensor."""
     nseg = seg_ends.numel()
-    buf = torch.empty((3, nseg), dtype=torch.float32, device=w.device)
+    buf = torch.empty(3 * nseg + _sqnorm_scratch(w.numel()), dtype=torch.float32, device=w.device)
     check(lib().ddl_segmented_sqnorms(ptr(w), ptr(g), ctypes.c_int(int(g.dtype == torch.bfloat16)),
                                       ptr(seg_offsets), ptr(seg_ends), ctypes.c_int(nseg),
-                                      _i64(w.numel()), ptr(buf), stream()), "segmented_sqnorms")
+                                      _i64(w.numel()), ptr(buf), ctypes.c_void_p(buf.data_ptr() + 12 * nseg),
+                                      stream()), "segmented_sqnorms")
     check(lib().ddl_lars_trust_ratios(ptr(buf), ctypes.c_int(nseg), _f32(trust_coefficient), _f32(wd), _f32(eps),
                                       ctypes.c_void_p(buf.data_ptr() + 8 * nseg), stream()), "lars_trust_ratios")
-    return buf[2]
+    return buf[2 * nseg: 3 * nseg]
 
 
 def fused_lars_(w, g, v, lowp, ratios, seg_offsets, seg_ends, lr, mu, wd, lr_scale=None) -> None:

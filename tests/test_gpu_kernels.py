@@ -1399,3 +1399,39 @@ def test_raw_addresses_handed_to_the_weight_gradient_stream_are_kept_alive():
     finally:
         hip._conv_wgrad = real
     assert len(seen) >= 2 and all(seen), seen     # the two stage-1 blocks of ResNet-18
+
+
+def test_segmented_norms_are_deterministic_and_exact():
+    """LARS pass 1 without float atomics: segments inside one 8192-element chunk, segments crossing one border,
+    segments covering many chunks, an empty segment and zero padding between segments - against fp64, and bit for
+    bit the same on every call."""
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    K.require()
+    g_ = torch.Generator(device=DEV).manual_seed(17)
+    lens = [64, 64, 8000, 100, 9000, 0, 300000, 256, 8192 * 3, 5, 70000]
+    starts, ends, pos = [], [], 0
+    for n in lens:
+        starts.append(pos)
+        ends.append(pos + n)
+        pos += (n + 63) // 64 * 64 + 64          # padded, with a gap
+    total = pos
+    w = torch.zeros(total, device=DEV)
+    g = torch.zeros(total, device=DEV)
+    for a, b in zip(starts, ends):
+        w[a:b] = torch.randn(b - a, generator=g_, device=DEV)
+        g[a:b] = torch.randn(b - a, generator=g_, device=DEV) * 0.1
+    so = torch.tensor(starts, dtype=torch.int64, device=DEV)
+    se = torch.tensor(ends, dtype=torch.int64, device=DEV)
+    for gg in (g, g.to(BF)):
+        wn, gn = K.segmented_norms(w, gg, so, se)
+        ref_w = torch.stack([w[a:b].double().pow(2).sum().sqrt() for a, b in zip(starts, ends)])
+        ref_g = torch.stack([gg[a:b].double().pow(2).sum().sqrt() for a, b in zip(starts, ends)])
+        assert torch.allclose(wn.double(), ref_w, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(gn.double(), ref_g, rtol=1e-5, atol=1e-6)
+        for _ in range(3):
+            wn2, gn2 = K.segmented_norms(w, gg, so, se)
+            assert torch.equal(wn2, wn) and torch.equal(gn2, gn)
+    r1 = K.lars_trust_ratios(w, g, so, se, 0.001, 5e-5, 1e-9).clone()
+    r2 = K.lars_trust_ratios(w, g, so, se, 0.001, 5e-5, 1e-9)
+    assert torch.equal(r1, r2) and float(r1[5]) == 1.0       # (empty segment: ratio 1)
