@@ -845,11 +845,18 @@ def _lin_ds_static_ok(wd, ds_stride, x):
         wd.shape[1] <= _DS_LINEAR["max_cin"]
 
 
-def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
+# the input gradient and the raw weight-gradient product g^T z2 of a linear unit in ONE pass over g
+# (csrc/kernels/lin_fused.hip; DDL_LIN_FUSED=0: the two-segment GEMM + a separate weight-gradient launch)
+_LIN_FUSED = {"on": _os.environ.get("DDL_LIN_FUSED", "1") != "0"}
+
+
+def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev, fuse=None):
     """Input gradient of the 1x1 conv behind the BatchNorm whose backward coefficients are in
     ``coef_t``: g [B, C, H, W] is that BatchNorm's (ReLU-masked) output gradient, z2 the conv's
     input.  Returns (g2, partial) like _conv_dgrad_bn: the ReLU-masked gradient of the previous
-    unit's BatchNorm output and its backward partial sums."""
+    unit's BatchNorm output and its backward partial sums.  ``fuse`` (a dict, or None): where the fused kernel
+    serves the shape it also computes the slabs of g^T z2 and leaves them in ``fuse["P"]`` ([splits, C*C2] fp32,
+    ``fuse["splits"]``) for :func:`_bn3_linear_wgrad_start`."""
     B, C, H, W = g.shape
     C2 = z2.shape[1]
     dev = g.device
@@ -876,7 +883,16 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev):
     if y_prev is None:   # plain store (projection shortcut: the result is the addend of the block-input gradient)
         K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, x2=z2, w2=q, c2=C2, bias=bias)
         return g2, None
-    T = K.conv_tiles_m_bwd(B * H * W, H, W, 1, 1)
+    M = B * H * W
+    nwg = K.lin_fused_wgs(M, C, C2) if (fuse is not None and _LIN_FUSED["on"]) else 0
+    if nwg > 0 and g.stride() == (H * W * C, 1, W * C, C) and z2.stride() == (H * W * C2, 1, W * C2, C2) and \
+            y_prev.stride() == z2.stride():
+        partial = torch.empty((nwg, 2, C2), dtype=torch.float32, device=dev)
+        P = torch.empty((nwg, C * C2), dtype=torch.float32, device=dev)
+        K.lin_fused(g, z2, b1, q, bias, y_prev, fcoef_prev, g2, partial, P, M, C, C2, nwg)
+        fuse["P"], fuse["splits"] = P, nwg
+        return g2, partial
+    T = K.conv_tiles_m_bwd(M, H, W, 1, 1)
     partial = torch.empty((T, 2, C2), dtype=torch.float32, device=dev)
     K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, stats=partial, ep_y=y_prev,
                  ep_fcoef=fcoef_prev, x2=z2, w2=q, c2=C2, bias=bias)
@@ -952,18 +968,21 @@ def _bn3_linear_gram_forward(z2, w):
     return pre
 
 
-def _bn3_linear_wgrad_start(g, z2, w, prewaited=False, pre=None):
+def _bn3_linear_wgrad_start(g, z2, w, prewaited=False, pre=None, raw_product=None):
     """First half of :func:`_bn3_linear_wgrad`: everything that needs no BatchNorm coefficients (the raw
-    product g^T z2 and, unless ``pre`` has it, the Gram part).  Returns the state for the second half."""
+    product g^T z2 - unless ``raw_product`` = {"P", "splits"} brings it from the fused input-gradient kernel; the
+    second half must then be ordered behind the main stream once more - and, unless ``pre`` has it, the Gram part).
+    Returns the state for the second half."""
     C, C2 = w.shape[0], w.shape[1]
     direct = _grad_listeners is not None and _direct_grad_ok(w) and _DIRECT["on"]
     out = w.grad if direct else torch.zeros_like(w)
     side = _side_stream(g.device) if (_SIDE["on"] and direct and g.shape[2] * g.shape[3] < _SIDE_MAX_HW) else None
     B, _, H, W = g.shape
     M = B * H * W
-    splits = K.conv_wgrad_splits(M, C, C2, 1, 1)      # raw product g^T z2
+    rawP = raw_product["P"] if raw_product else None
+    splits = raw_product["splits"] if rawP is not None else K.conv_wgrad_splits(M, C, C2, 1, 1)      # raw product g^T z2
     slab = C * C2
-    pbytes = (4 * splits * slab + 255) // 256 * 256
+    pbytes = 0 if rawP is not None else (4 * splits * slab + 255) // 256 * 256
     tbytes = (2 * slab + 255) // 256 * 256
     total = pbytes + (0 if pre is not None else tbytes + 4 * 2 * C2 + 256 + _lin_gram_scratch_bytes(M, C, C2))
     ws_t = None
@@ -975,8 +994,11 @@ def _bn3_linear_wgrad_start(g, z2, w, prewaited=False, pre=None):
         if not prewaited:
             K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
         base = _side_workspace(total)
-    partial = base
-    K.conv_wgrad(g, z2, _geom(z2), partial, C, 1, 1, 1, 0, 0, H, W, splits, stream=raw)
+    if rawP is not None:
+        partial = rawP.data_ptr()
+    else:
+        partial = base
+        K.conv_wgrad(g, z2, _geom(z2), partial, C, 1, 1, 1, 0, 0, H, W, splits, stream=raw)
     if pre is not None:
         t = pre.data_ptr()
         colz = t + tbytes
@@ -984,14 +1006,14 @@ def _bn3_linear_wgrad_start(g, z2, w, prewaited=False, pre=None):
         t = base + pbytes
         colz = t + tbytes
         _bn3_linear_gram(z2, w, raw, colz + 8 * C2, t, colz)   # (8*C2 bytes of column sums; C2 % 64 == 0 keeps the alignment)
-    return (g, z2, w, pre, direct, out, side, raw, partial, slab, splits, t, colz, C, C2, ws_t)
+    return (g, z2, w, pre, direct, out, side, raw, partial, slab, splits, t, colz, C, C2, ws_t, rawP)
 
 
 def _bn3_linear_wgrad_finish(state, coef_t, coeffs, coef_late=False):
     """Second half: the split-K reduction that applies the coefficients.  ``coef_late``: the side stream
     was ordered behind the main one BEFORE the coefficients were computed there - wait again."""
-    g, z2, w, pre, direct, out, side, raw, partial, slab, splits, t, colz, C, C2, ws_t = state
-    if coef_late and raw is not None:
+    g, z2, w, pre, direct, out, side, raw, partial, slab, splits, t, colz, C, C2, ws_t, rawP = state
+    if (coef_late or rawP is not None) and raw is not None:
         K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
     K.splitk_reduce_lin(partial, out, slab, splits, slab, direct, coef_t.data_ptr(), C, t, colz, C2,
                         coeffs.data_ptr(), stream=raw)
@@ -1001,9 +1023,9 @@ def _bn3_linear_wgrad_finish(state, coef_t, coeffs, coef_late=False):
         # the allocator would hand their memory to the main stream while the reduction is still queued
         _side_mark_used()
         if _SIDE["join_queued"]:
-            _SIDE["keep"].append((g, z2, coef_t, coeffs, pre))
+            _SIDE["keep"].append((g, z2, coef_t, coeffs, pre, rawP))
         else:
-            for t_ in (g, z2, coef_t, coeffs) + ((pre,) if pre is not None else ()):
+            for t_ in (g, z2, coef_t, coeffs) + ((pre,) if pre is not None else ()) + ((rawP,) if rawP is not None else ()):
                 t_.record_stream(side)
     if direct:
         _notify(w)
@@ -1487,10 +1509,12 @@ class ResidualBlockFn(Function):
                 # the dependent chain first (the host is what the main stream waits for in the late
                 # layers: issuing the side-stream work first left 40-140 us holes in front of the prep kernel)
                 pre = early or _side_prewait(dz.device)   # the side stream may start before the chain's next kernels finish
+                lf = {} if wstate is None else None      # (the raw product may ride in the input-gradient kernel)
                 dz, fused = _bn3_linear_dgrad(g_short, inp, w, coef_t, ys[i - 1],
-                                              cs[i - 1].data_ptr() + 8 * inp.shape[1])
+                                              cs[i - 1].data_ptr() + 8 * inp.shape[1], fuse=lf)
                 if wstate is None:
-                    wstate = _bn3_linear_wgrad_start(g_short, inp, w, prewaited=pre, pre=getattr(ctx, "lin_pre", None))
+                    wstate = _bn3_linear_wgrad_start(g_short, inp, w, prewaited=pre, pre=getattr(ctx, "lin_pre", None),
+                                                     raw_product=lf if lf else None)
                 dw = _bn3_linear_wgrad_finish(wstate, coef_t, cs[i], coef_late=bool(early))
                 put(i, dw, dg, db)
                 _flush_notifications()

@@ -460,6 +460,21 @@ def splitk_reduce_lin(partial, out, n, splits, slab, accumulate, coef, C, T, col
             _raw_stream() if stream is None else stream), "splitk_reduce_lin")
 
 
+@functools.lru_cache(maxsize=None)
+def lin_fused_wgs(M, C, C2):
+    """Workgroups (= slabs of the raw product, = statistics rows) of :func:`lin_fused` for M pixels, or 0 when the
+    fused kernel does not serve the shape (csrc/kernels/lin_fused.hip: 256 wide / 64 narrow channels)."""
+    return int(lib().ddl_lin_fused_wgs(_i64(M), _i32(C), _i32(C2)))
+
+
+def lin_fused(g, z2, b1, q, bias, y_prev, fcoef, g2, stats, partial, M, C, C2, nwg, stream=None):
+    """One pass over g [M][C] and z2 [M][C2]: g2 = mask(g b1^T + z2 q^T + bias) (masked by relu'(bn(y_prev)), with
+    the sums sum g2 | sum g2*y_prev in ``stats`` [nwg][2][C2]) and the slabs of g^T z2 in ``partial`` [nwg][C][C2]."""
+    f = _fn("ddl_lin_fused", "pppppppppp qiii p")
+    check(f(_p(g), _p(z2), _p(b1), _p(q), _p(bias), _p(y_prev), _p(fcoef), _p(g2), _p(stats), _p(partial),
+            M, C, C2, nwg, _raw_stream() if stream is None else stream), "lin_fused")
+
+
 def splitk_reduce_centered(partial, out, C, splits, colz, M, stream=None):
     """out (bf16 [C][C]) = sum_s partial[s] - colz (x) colz / M (centred in fp32, rounded once)."""
     f = _fn("ddl_splitk_reduce_centered", "pp ii p q p")

@@ -1435,3 +1435,116 @@ def test_segmented_norms_are_deterministic_and_exact():
     r1 = K.lars_trust_ratios(w, g, so, se, 0.001, 5e-5, 1e-9).clone()
     r2 = K.lars_trust_ratios(w, g, so, se, 0.001, 5e-5, 1e-9)
     assert torch.equal(r1, r2) and float(r1[5]) == 1.0       # (empty segment: ratio 1)
+
+
+def test_lin_fused_kernel_against_the_two_kernels_it_replaces():
+    """lin_fused.hip: the masked input gradient of a linear unit, its BatchNorm-backward sums and the raw
+    weight-gradient product g^T z2 in one pass over g - against the two-segment tile kernel (bit-identical g2: same
+    reduction order) and the split-K weight-gradient kernel (equal to fp32 rounding), and against fp32."""
+    from distributeddeeplearning_amd.ops import hip_ops as hip
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    K.require()
+    B, H, W, C, C2 = 11, 56, 56, 256, 64
+    M = B * H * W
+    nwg = K.lin_fused_wgs(M, C, C2)
+    if nwg == 0:
+        pytest.skip("fused kernel switched off")
+    g = rand_nhwc(B, C, H, W, seed=91)
+    z2 = torch.relu(rand_nhwc(B, C2, H, W, seed=92))
+    y_prev = rand_nhwc(B, C2, H, W, seed=93)
+    gen = torch.Generator(device=DEV).manual_seed(94)
+    b1 = (torch.randn((C2, C), generator=gen, device=DEV) / 16).to(BF)
+    q = (torch.randn((C2, C2), generator=gen, device=DEV) / 8).to(BF)
+    bias = torch.randn(C2, generator=gen, device=DEV) * 0.1
+    fco = torch.stack([torch.rand(C2, generator=gen, device=DEV) + 0.5, torch.randn(C2, generator=gen, device=DEV) * 0.3]).contiguous()
+    # the two kernels
+    g2_ref = torch.empty_like(z2)
+    T = K.conv_tiles_m_bwd(M, H, W, 1, 1)
+    st_ref = torch.empty((T, 2, C2), device=DEV)
+    K.conv_igemm(g, hip._geom(g), b1, g2_ref, C2, 1, 1, 1, 0, 0, 1, H, W, stats=st_ref, ep_y=y_prev, ep_fcoef=fco,
+                 x2=z2, w2=q, c2=C2, bias=bias)
+    splits = K.conv_wgrad_splits(M, C, C2, 1, 1)
+    p_ref = torch.empty((splits, C * C2), device=DEV)
+    K.conv_wgrad(g, z2, hip._geom(z2), p_ref, C, 1, 1, 1, 0, 0, H, W, splits)
+    # the fused kernel
+    g2 = torch.full_like(z2, float("nan"))
+    st = torch.full((nwg, 2, C2), float("nan"), device=DEV)
+    P = torch.full((nwg, C * C2), float("nan"), device=DEV)
+    K.lin_fused(g, z2, b1, q, bias, y_prev, fco, g2, st, P, M, C, C2, nwg)
+    assert torch.equal(g2, g2_ref)
+    assert torch.allclose(st.sum(0), st_ref.sum(0), rtol=2e-4, atol=1e-2)
+    assert torch.allclose(P.sum(0), p_ref.sum(0), rtol=1e-4, atol=1e-2)
+    # fp32 references
+    gm = g.permute(0, 2, 3, 1).reshape(M, C).float()
+    zm = z2.permute(0, 2, 3, 1).reshape(M, C2).float()
+    ym = y_prev.permute(0, 2, 3, 1).reshape(M, C2).float()
+    full = gm @ b1.float().t() + zm @ q.float().t() + bias
+    on = (ym * fco[0] + fco[1]) > 0
+    ref = torch.where(on, full, torch.zeros_like(full))
+    got = g2.permute(0, 2, 3, 1).reshape(M, C2).float()
+    flips = (on != (got != 0)) & (full.abs() > 1e-3)          # (elements at the ReLU threshold may flip with the fma rounding)
+    assert float(flips.float().mean()) < 1e-4
+    assert rms_relerr(torch.where(flips, ref, got), ref) < 4e-3
+    assert rms_relerr(P.sum(0).view(C, C2), gm.t() @ zm) < 1e-4
+    # deterministic
+    P2 = torch.empty_like(P)
+    st2 = torch.empty_like(st)
+    K.lin_fused(g, z2, b1, q, bias, y_prev, fco, torch.empty_like(z2), st2, P2, M, C, C2, nwg)
+    assert torch.equal(P2, P) and torch.equal(st2, st)
+
+
+def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form():
+    """Two stage-1 bottlenecks on 56 x 56 images with the fused input-gradient / raw-product kernel on and off:
+    every gradient agrees to the accuracy of the different summation orders (the slabs are cut differently)."""
+    from distributeddeeplearning_amd.models.resnet import Bottleneck, _block_spec
+    from distributeddeeplearning_amd.ops import functional as ops
+
+    hip = _hip()
+    from distributeddeeplearning_amd.ops import kernels as K
+    if K.lin_fused_wgs(11 * 56 * 56, 256, 64) == 0:
+        pytest.skip("fused kernel switched off")
+
+    def make():
+        torch.manual_seed(19)
+        ms = [Bottleneck(64, 64, 1, True, False), Bottleneck(256, 64, 1, False, False), Bottleneck(256, 64, 1, False, False)]
+        for m in ms:
+            m.to(DEV).train()
+            for mod in m.modules():
+                if hasattr(mod, "kernel"):
+                    mod.weight.data = mod.weight.data.to(BF).contiguous(memory_format=CL)
+        return ms
+
+    x0 = torch.relu(rand_nhwc(11, 64, 56, 56, seed=95))
+    gout = rand_nhwc(11, 256, 56, 56, seed=96)
+    used = {"n": 0}
+    real = K.lin_fused
+
+    def counting(*a, **k):
+        used["n"] += 1
+        return real(*a, **k)
+
+    def run(on):
+        hip.reset_caches()
+        ms = make()
+        x = x0.detach().clone().requires_grad_(True)
+        saved = hip._LIN_FUSED["on"]
+        hip._LIN_FUSED["on"] = on
+        K.lin_fused = counting
+        try:
+            out = ops.residual_chain(x, [_block_spec(m.pairs(), m.downsample) for m in ms], True, 0.1, 1e-5)
+            out.backward(gout)
+            torch.cuda.synchronize()
+        finally:
+            hip._LIN_FUSED["on"] = saved
+            K.lin_fused = real
+        names = [n for m in ms for n, _ in m.named_parameters()]
+        return x.grad, names, [p.grad.float().clone() for m in ms for p in m.parameters()]
+
+    dx_a, names, g_a = run(True)
+    assert used["n"] == 2, used            # the two blocks whose incoming gradient is pre-masked
+    dx_b, _, g_b = run(False)
+    assert used["n"] == 2
+    assert rms_relerr(dx_a, dx_b) < 2e-3
+    for n, a, b in zip(names, g_a, g_b):
+        assert rms_relerr(a, b) < 5e-3, (n, rms_relerr(a, b))
