@@ -43,6 +43,9 @@ __device__ __forceinline__ void lf_store16(u32x4 rsrc, unsigned voff, unsigned s
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rsrc), "s"(soff));
 }
 
+// MASK = false: plain store of g B1^T + z2 Q^T + bias (the projection shortcut's linear unit: the result is the addend
+// of the block-input gradient), no y_prev, no statistics.
+template <bool MASK>
 __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) {
     constexpr int C = 256, C2 = 64, BM = 64;
     constexpr int GROW = C * 2, ZROW = C2 * 2;                        // bytes per pixel row
@@ -62,7 +65,7 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
     if (T < 0) T = 0;
 
     const unsigned g_bytes = (unsigned)((long long)p.M * GROW), z_bytes = (unsigned)((long long)p.M * ZROW);
-    const u32x4 gr = raw_rsrc(p.g, g_bytes), zr = raw_rsrc(p.z2, z_bytes), yr = raw_rsrc(p.y_prev, z_bytes);
+    const u32x4 gr = raw_rsrc(p.g, g_bytes), zr = raw_rsrc(p.z2, z_bytes), yr = raw_rsrc(MASK ? p.y_prev : p.z2, z_bytes);
     const u32x4 or_ = raw_rsrc(p.g2, z_bytes);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
 
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
         *reinterpret_cast<u32x4*>(smem + WQ + rho * ZROW + ((ch ^ (rho & 7)) << 4)) = v;
     }
     if (tid < 64) reinterpret_cast<float*>(smem + FB)[tid] = p.bias[tid];
-    else if (tid < 192) reinterpret_cast<float*>(smem + FB)[tid] = p.fcoef[tid - 64];
+    else if (MASK && tid < 192) reinterpret_cast<float*>(smem + FB)[tid] = p.fcoef[tid - 64];
 
     // ---- DMA geometry (6 instructions per thread and tile; the swizzles are applied on the source side)
     //      g tile: rows of 512 B, 32-byte window w of row r at window w ^ (r & 7)   (conv_wgrad256's layout)
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_dma16(gr, St + i * 8192, live ? g_voff[i] : INVALID, tile * (unsigned)GT);
         lds_dma16(zr, St + GT, live ? z_voff : INVALID, tile * (unsigned)ZT);
-        lds_dma16(yr, St + GT + ZT, live ? (unsigned)(tid * 16) : INVALID, tile * (unsigned)ZT);
+        lds_dma16(yr, St + GT + ZT, (live && MASK) ? (unsigned)(tid * 16) : INVALID, tile * (unsigned)ZT);   // (always issued: the counted wait)
     };
 
     // ---- input-gradient role: pixel fragment mf (pixels 16 mf + fr of the tile), channel pair a (channels 32 a ..)
@@ -146,8 +149,10 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
     __builtin_amdgcn_s_barrier();
     float bia[8], fsc[8], fsh[8];
     load8f(reinterpret_cast<const float*>(smem + FB) + c8, bia);
-    load8f(reinterpret_cast<const float*>(smem + FB) + 64 + c8, fsc);
-    load8f(reinterpret_cast<const float*>(smem + FB) + 128 + c8, fsh);
+    if (MASK) {
+        load8f(reinterpret_cast<const float*>(smem + FB) + 64 + c8, fsc);
+        load8f(reinterpret_cast<const float*>(smem + FB) + 128 + c8, fsh);
+    }
 
     for (int t = 0; t < T; ++t) {
         const int stage = t & 1;
@@ -184,11 +189,15 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float a = (e < 4 ? accd[0][e & 3] : accd[1][e & 3]) + bia[e];
-                const float yf = bf2f(yv[e]);
-                const bool on = bn_affine(yf, fsc[e], fsh[e]) > 0.f;
-                v[e] = on ? f2bf(a) : f2bf(0.f);
-                const float gg = bf2f(v[e]);
-                s1[e] += gg; s2[e] += gg * yf;
+                if (MASK) {
+                    const float yf = bf2f(yv[e]);
+                    const bool on = bn_affine(yf, fsc[e], fsh[e]) > 0.f;
+                    v[e] = on ? f2bf(a) : f2bf(0.f);
+                    const float gg = bf2f(v[e]);
+                    s1[e] += gg; s2[e] += gg * yf;
+                } else {
+                    v[e] = f2bf(a);
+                }
             }
             lf_store16(or_, (unsigned)((mrow * C2 + c8) * 2), (unsigned)(tile0 + t) * (unsigned)ZT, __builtin_bit_cast(u32x4, v));
         }
@@ -232,6 +241,7 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
             for (int e = 0; e < 4; ++e)
                 out[((2 * wid + i) * 16 + fq * 4 + e) * C2 + j * 16 + fr] = accw[i][j][e];
 
+    if (!MASK) return;
     // ---- statistics row: fold the 16 pixel lanes, then the four pixel fragments (fixed order)
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -273,10 +283,11 @@ extern "C" int ddl_lin_fused_wgs(long long M, int C, int C2) {
 extern "C" int ddl_lin_fused(const void* g, const void* z2, const void* b1, const void* q, const void* bias,
                              const void* y_prev, const void* fcoef, void* g2, void* stats, void* partial,
                              long long M, int C, int C2, int nwg, hipStream_t stream) {
-    if (!g || !z2 || !b1 || !q || !bias || !y_prev || !fcoef || !g2 || !stats || !partial) return DDL_EINVAL;
+    if (!g || !z2 || !b1 || !q || !bias || !g2 || !partial) return DDL_EINVAL;
+    if ((y_prev == nullptr) != (fcoef == nullptr) || (y_prev == nullptr) != (stats == nullptr)) return DDL_EINVAL;
     if (nwg <= 0 || nwg != ddl_lin_fused_wgs(M, C, C2)) return DDL_EINVAL;
     const void* al[] = {g, z2, b1, q, bias, y_prev, fcoef, g2, stats, partial};
-    for (const void* a : al) if (!ddl_aligned16(a)) return DDL_EALIGN;
+    for (const void* a : al) if (a && !ddl_aligned16(a)) return DDL_EALIGN;
     LinFusedParams p;
     p.g = (const bf16_t*)g; p.z2 = (const bf16_t*)z2; p.b1 = (const bf16_t*)b1; p.q = (const bf16_t*)q;
     p.bias = (const float*)bias; p.y_prev = (const bf16_t*)y_prev; p.fcoef = (const float*)fcoef;
@@ -284,6 +295,7 @@ extern "C" int ddl_lin_fused(const void* g, const void* z2, const void* b1, cons
     p.M = (int)M;
     const long long tiles = M / 64;
     p.tiles_per_wg = (int)((tiles + nwg - 1) / nwg);
-    DDL_KLAUNCH(lin_fused_kernel, dim3(nwg), dim3(512), 0, stream, p);
+    if (y_prev) DDL_KLAUNCH(lin_fused_kernel<true>, dim3(nwg), dim3(512), 0, stream, p);
+    else DDL_KLAUNCH(lin_fused_kernel<false>, dim3(nwg), dim3(512), 0, stream, p);
     return ddl_launch_status();
 }

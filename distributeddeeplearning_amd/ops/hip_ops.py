@@ -880,18 +880,18 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev, fuse=None):
         if _LIN_PREP_Q < 0:   # timing probe: the chain's price of this GEMM (issued twice)
             K.conv_igemm(a2, (C2, 1, 1, C, C, C, C, a2.numel()), wt3, q, C2, 1, 1, 1, 0, 0, 1, 1, 1)
     g2 = _empty_nhwc(B, C2, H, W, dev)
-    if y_prev is None:   # plain store (projection shortcut: the result is the addend of the block-input gradient)
-        K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, x2=z2, w2=q, c2=C2, bias=bias)
-        return g2, None
     M = B * H * W
     nwg = K.lin_fused_wgs(M, C, C2) if (fuse is not None and _LIN_FUSED["on"]) else 0
     if nwg > 0 and g.stride() == (H * W * C, 1, W * C, C) and z2.stride() == (H * W * C2, 1, W * C2, C2) and \
-            y_prev.stride() == z2.stride():
-        partial = torch.empty((nwg, 2, C2), dtype=torch.float32, device=dev)
+            tuple(z2.shape[2:]) == (H, W) and (y_prev is None or y_prev.stride() == z2.stride()):
+        partial = None if y_prev is None else torch.empty((nwg, 2, C2), dtype=torch.float32, device=dev)
         P = torch.empty((nwg, C * C2), dtype=torch.float32, device=dev)
         K.lin_fused(g, z2, b1, q, bias, y_prev, fcoef_prev, g2, partial, P, M, C, C2, nwg)
         fuse["P"], fuse["splits"] = P, nwg
         return g2, partial
+    if y_prev is None:   # plain store (projection shortcut: the result is the addend of the block-input gradient)
+        K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, x2=z2, w2=q, c2=C2, bias=bias)
+        return g2, None
     T = K.conv_tiles_m_bwd(M, H, W, 1, 1)
     partial = torch.empty((T, 2, C2), dtype=torch.float32, device=dev)
     K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, stats=partial, ep_y=y_prev,
@@ -1033,13 +1033,13 @@ def _bn3_linear_wgrad_finish(state, coef_t, coeffs, coef_late=False):
     return out
 
 
-def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None, coef_late=False):
+def _bn3_linear_wgrad(g, z2, w, coef_t, coeffs, prewaited=False, pre=None, coef_late=False, raw_product=None):
     """dW3 by linearity, into ``w.grad`` when that is a live arena view (returns None and notifies),
     else returned.  Runs on the weight-gradient stream like _conv_wgrad: raw stream handle, one
     persistent workspace carved by address (no torch stream switch, no allocations).  ``pre``: the
     Gram part already computed during the forward pass (:func:`_bn3_linear_gram_forward`).
     ``coeffs``: the BatchNorm's saved [4, C] block (its first row, the batch mean, is read here)."""
-    return _bn3_linear_wgrad_finish(_bn3_linear_wgrad_start(g, z2, w, prewaited, pre), coef_t, coeffs, coef_late)
+    return _bn3_linear_wgrad_finish(_bn3_linear_wgrad_start(g, z2, w, prewaited, pre, raw_product), coef_t, coeffs, coef_late)
 
 
 class _RawOut:
@@ -1570,10 +1570,11 @@ class ResidualBlockFn(Function):
                             xs = x if ds_stride == 1 else K.subsample2(x)
                         coef_d, dgd, dbd = _unit_coef(g_short, yd, gd, bd, cd, fused_ds)
                         pre = _side_prewait(g_short.device)
-                        addend, _ = _bn3_linear_dgrad(g_short, xs, wd, coef_d, None, None)
+                        lfd = {}
+                        addend, _ = _bn3_linear_dgrad(g_short, xs, wd, coef_d, None, None, fuse=lfd)
                         sub2 = ds_stride == 2
                         dwd = _bn3_linear_wgrad(g_short, xs, wd, coef_d, cd, prewaited=pre,
-                                                pre=getattr(ctx, "lin_pre_ds", None))
+                                                pre=getattr(ctx, "lin_pre_ds", None), raw_product=lfd if lfd else None)
                         put(units, dwd, dgd, dbd)
                     else:
                         dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False,

@@ -1487,6 +1487,13 @@ def test_lin_fused_kernel_against_the_two_kernels_it_replaces():
     assert float(flips.float().mean()) < 1e-4
     assert rms_relerr(torch.where(flips, ref, got), ref) < 4e-3
     assert rms_relerr(P.sum(0).view(C, C2), gm.t() @ zm) < 1e-4
+    # without the mask (projection shortcut's unit): the plain two-segment GEMM
+    g2p_ref = torch.empty_like(z2)
+    K.conv_igemm(g, hip._geom(g), b1, g2p_ref, C2, 1, 1, 1, 0, 0, 1, H, W, x2=z2, w2=q, c2=C2, bias=bias)
+    g2p = torch.full_like(z2, float("nan"))
+    Pp = torch.full((nwg, C * C2), float("nan"), device=DEV)
+    K.lin_fused(g, z2, b1, q, bias, None, None, g2p, None, Pp, M, C, C2, nwg)
+    assert torch.equal(g2p, g2p_ref) and torch.equal(Pp, P)
     # deterministic
     P2 = torch.empty_like(P)
     st2 = torch.empty_like(st)
@@ -1542,9 +1549,9 @@ def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form():
         return x.grad, names, [p.grad.float().clone() for m in ms for p in m.parameters()]
 
     dx_a, names, g_a = run(True)
-    assert used["n"] == 2, used            # the two blocks whose incoming gradient is pre-masked
+    assert used["n"] == 3, used            # the two blocks whose incoming gradient is pre-masked + the first one's projection
     dx_b, _, g_b = run(False)
-    assert used["n"] == 2
+    assert used["n"] == 3
     assert rms_relerr(dx_a, dx_b) < 2e-3
     for n, a, b in zip(names, g_a, g_b):
         assert rms_relerr(a, b) < 5e-3, (n, rms_relerr(a, b))
