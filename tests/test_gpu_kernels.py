@@ -1437,7 +1437,8 @@ def test_segmented_norms_are_deterministic_and_exact():
     assert torch.equal(r1, r2) and float(r1[5]) == 1.0       # (empty segment: ratio 1)
 
 
-def test_lin_fused_kernel_against_the_two_kernels_it_replaces():
+@pytest.mark.parametrize("shape", [(11, 56, 256, 64), (44, 28, 512, 128)])
+def test_lin_fused_kernel_against_the_two_kernels_it_replaces(shape):
     """lin_fused.hip: the masked input gradient of a linear unit, its BatchNorm-backward sums and the raw
     weight-gradient product g^T z2 in one pass over g - against the two-segment tile kernel (bit-identical g2: same
     reduction order) and the split-K weight-gradient kernel (equal to fp32 rounding), and against fp32."""
@@ -1445,7 +1446,8 @@ def test_lin_fused_kernel_against_the_two_kernels_it_replaces():
     from distributeddeeplearning_amd.ops import kernels as K
 
     K.require()
-    B, H, W, C, C2 = 11, 56, 56, 256, 64
+    B, H, C, C2 = shape             # (stage 1: one workgroup per pixel range; stage 2: two, one per half of the narrow channels)
+    W = H
     M = B * H * W
     nwg = K.lin_fused_wgs(M, C, C2)
     if nwg == 0:
@@ -1501,20 +1503,25 @@ def test_lin_fused_kernel_against_the_two_kernels_it_replaces():
     assert torch.equal(P2, P) and torch.equal(st2, st)
 
 
-def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form():
-    """Two stage-1 bottlenecks on 56 x 56 images with the fused input-gradient / raw-product kernel on and off:
+@pytest.mark.parametrize("stage", [1, 2])
+def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form(stage):
+    """Three bottlenecks of stage 1 (56 x 56) or stage 2 (28 x 28) with the fused input-gradient / raw-product kernel on and off:
     every gradient agrees to the accuracy of the different summation orders (the slabs are cut differently)."""
     from distributeddeeplearning_amd.models.resnet import Bottleneck, _block_spec
     from distributeddeeplearning_amd.ops import functional as ops
 
     hip = _hip()
     from distributeddeeplearning_amd.ops import kernels as K
-    if K.lin_fused_wgs(11 * 56 * 56, 256, 64) == 0:
+    B = 11 if stage == 1 else 44
+    if (K.lin_fused_wgs(B * 56 * 56, 256, 64) if stage == 1 else K.lin_fused_wgs(B * 28 * 28, 512, 128)) == 0:
         pytest.skip("fused kernel switched off")
 
     def make():
         torch.manual_seed(19)
-        ms = [Bottleneck(64, 64, 1, True, False), Bottleneck(256, 64, 1, False, False), Bottleneck(256, 64, 1, False, False)]
+        if stage == 1:
+            ms = [Bottleneck(64, 64, 1, True, False), Bottleneck(256, 64, 1, False, False), Bottleneck(256, 64, 1, False, False)]
+        else:
+            ms = [Bottleneck(256, 128, 2, True, False), Bottleneck(512, 128, 1, False, False), Bottleneck(512, 128, 1, False, False)]
         for m in ms:
             m.to(DEV).train()
             for mod in m.modules():
@@ -1522,8 +1529,8 @@ def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form():
                     mod.weight.data = mod.weight.data.to(BF).contiguous(memory_format=CL)
         return ms
 
-    x0 = torch.relu(rand_nhwc(11, 64, 56, 56, seed=95))
-    gout = rand_nhwc(11, 256, 56, 56, seed=96)
+    x0 = torch.relu(rand_nhwc(B, 64 if stage == 1 else 256, 56, 56, seed=95))
+    gout = rand_nhwc(B, 256, 56, 56, seed=96) if stage == 1 else rand_nhwc(B, 512, 28, 28, seed=96)
     used = {"n": 0}
     real = K.lin_fused
 
@@ -1549,9 +1556,10 @@ def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form():
         return x.grad, names, [p.grad.float().clone() for m in ms for p in m.parameters()]
 
     dx_a, names, g_a = run(True)
-    assert used["n"] == 3, used            # the two blocks whose incoming gradient is pre-masked + the first one's projection
+    want = 3 if stage == 1 else 2          # the two blocks whose incoming gradient is pre-masked (+ stage 1: the projection's unit)
+    assert used["n"] == want, used
     dx_b, _, g_b = run(False)
-    assert used["n"] == 3
+    assert used["n"] == want
     assert rms_relerr(dx_a, dx_b) < 2e-3
     for n, a, b in zip(names, g_a, g_b):
         assert rms_relerr(a, b) < 5e-3, (n, rms_relerr(a, b))
