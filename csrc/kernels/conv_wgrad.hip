@@ -1055,7 +1055,9 @@ static bool wgrad_rows(int K, int C, int R, int S, int Hout, int Wout, int strid
     return Hout % rs == 0;
 }
 static int wgrad_rows_ips(int K, int B) {
-    static const int target = getenv("DDL_WGRAD_ROWS_TARGET") ? atoi(getenv("DDL_WGRAD_ROWS_TARGET")) : 256;  // tuning knob
+    // (re-swept on the final tree of round 3: 256 / 192 / 128 / 64 workgroups -> 16.30 / 16.27 / 16.23 / 16.24 ms per step,
+    // ResNet-34 9.60 -> 9.44, ResNet-18 5.47 -> 5.40 for 256 -> 128: two images per workgroup leave half the CUs to the chain)
+    static const int target = getenv("DDL_WGRAD_ROWS_TARGET") ? atoi(getenv("DDL_WGRAD_ROWS_TARGET")) : 128;  // tuning knob
     int nsplit = target / (K / 64);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > B) nsplit = B;
