@@ -38,6 +38,8 @@ struct LinFusedParams {
     bf16_t* g2;             // [M][K2]
     float* stats;           // [ranges][2][K2]  sum g2 | sum g2 * y_prev
     float* partial;         // [ranges][C][K2] fp32 slabs of g^T z2
+    float* gram;            // GRAM: [ranges][K2][K2] fp32 slabs of z2^T z2
+    float* colsum;          // GRAM: [ranges][2][K2] column sums of z2 (both rows alike: a statistics-table layout)
     int M, tiles_per_wg, ranges;
 };
 
@@ -52,7 +54,9 @@ __device__ __forceinline__ void lf_store16(u32x4 rsrc, unsigned voff, unsigned s
 // A workgroup produces 64 output channels (all of them for K2 = 64, half h for K2 = 128 with HALVES = 2).
 // MASK = false: plain store of g B1^T + z2 Q^T + bias (the projection shortcut's linear unit: the result is the addend
 // of the block-input gradient), no y_prev, no statistics.
-template <int C, int K2, int BM, int HALVES, bool MASK>
+// GRAM: the Gram matrix z2^T z2 and the column sums of z2 (the forward-data part of the linear weight gradient) are
+// accumulated from the z2 tile as well: their own launch - another pass over z2 on the weight-gradient stream - disappears.
+template <int C, int K2, int BM, int HALVES, bool MASK, bool GRAM>
 __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) {
     static_assert(K2 == 64 * HALVES && (BM == 32 || BM == 64) && C % 128 == 0, "64 output channels per workgroup");
     constexpr int GROW = C * 2, ZROW = K2 * 2, YROW = 128;            // bytes per pixel row (y_prev tile: this half only)
@@ -146,6 +150,12 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
         for (int ks = 0; ks < KSZ; ++ks)
             qa[I][ks] = *reinterpret_cast<const bf16x8*>(p.q + (long long)(h * 64 + chan_of(rho)) * K2 + (4 * ks + fq) * 8);
     }
+    // (pinned: under register pressure hipcc otherwise re-loads these from global memory INSIDE the tile loop, and its
+    // `s_waitcnt vmcnt(0)` in front of their use drains the LDS-DMA ring every tile - 187 -> 762 us)
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int ks = 0; ks < KSZ; ++ks) asm volatile("" : "+v"(qa[I][ks]));
     const int c8 = 32 * pa + 8 * fq;          // this lane's 8 output channels (inside the half)
     // ---- raw-product role: wide-channel fragments CF wid .. against the four narrow fragments of the half
     const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
@@ -164,6 +174,25 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    // ---- Gram role: K2 / 16 row windows x the 4 column windows of this half = GW fragments per wave
+    constexpr int NWIN = K2 / 16, GW = NWIN * 4 / 8;          // 2 (K2 = 64) or 4 (K2 = 128)
+    const int g_wi = GW == 2 ? (wid >> 1) : wid;              // row window of this wave
+    const int g_j0 = GW == 2 ? 2 * (wid & 1) : 0;             // its first column window (inside the half)
+    const int zg_off = GT + tr_row * ZROW + ((g_wi ^ zswz(tr_row)) << 5) + 8 * tp;
+    int zgb_off[GW];      // (its column fragments are read again rather than picked out of bf_[] by a run-time index:
+                          //  hipcc turns that into a thousand v_cndmask per tile)
+#pragma unroll
+    for (int i = 0; i < GW; ++i) zgb_off[i] = GT + tr_row * ZROW + (((4 * h + g_j0 + i) ^ zswz(tr_row)) << 5) + 8 * tp;
+    f32x4 accg[GRAM ? GW : 1], accs[GRAM ? 4 : 1];
+    bf16x8 ones;
+    if (GRAM) {
+#pragma unroll
+        for (int i = 0; i < GW; ++i) accg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = f2bf(1.f);
+    }
 
     fetch(0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the weight image
@@ -243,6 +272,22 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     accw[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], accw[i][j], 0, 0, 0);
+            if (GRAM) {
+                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lf_lds_bf16x4_ptr)(Zk + zg_off));
+                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lf_lds_bf16x4_ptr)(Zk + zg_off + 16 * ZROW));
+                const bf16x8 zg = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int i = 0; i < GW; ++i) {
+                    bf16x4 l2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lf_lds_bf16x4_ptr)(Zk + zgb_off[i]));
+                    bf16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lf_lds_bf16x4_ptr)(Zk + zgb_off[i] + 16 * ZROW));
+                    const bf16x8 gb = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+                    accg[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zg, gb, accg[i], 0, 0, 0);
+                }
+                if (wid == 0) {      // a row of ones through the matrix pipe: every D row holds the column sums
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf_[j], accs[j], 0, 0, 0);
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();         // everybody is done with this stage: the DMA of tile t+2 may overwrite it
@@ -259,6 +304,21 @@ __global__ void __launch_bounds__(512) lin_fused_kernel(const LinFusedParams p) 
             for (int e = 0; e < 4; ++e)
                 out[((CF * wid + i) * 16 + fq * 4 + e) * K2 + h * 64 + j * 16 + fr] = accw[i][j][e];
 
+    if (GRAM) {
+        float* go = p.gram + (long long)range * K2 * K2;
+#pragma unroll
+        for (int i = 0; i < GW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                go[(g_wi * 16 + fq * 4 + e) * K2 + h * 64 + (g_j0 + i) * 16 + fr] = accg[i][e];
+        if (wid == 0 && fq == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p.colsum[((long long)range * 2) * K2 + h * 64 + j * 16 + fr] = accs[j][0];
+                p.colsum[((long long)range * 2 + 1) * K2 + h * 64 + j * 16 + fr] = accs[j][0];
+            }
+        }
+    }
     if (!MASK) return;
     // ---- statistics row: fold the 16 pixel lanes, then the pixel fragments (fixed order)
 #pragma unroll
@@ -311,10 +371,19 @@ extern "C" int ddl_lin_fused_wgs(long long M, int C, int C2) {
     return (int)ranges;
 }
 
+// 1 when the fused launch of this shape can also accumulate the Gram matrix and the column sums of z2 (stage 1: the
+// two-workgroup form of stage 2 has no registers left for it - 16 spilled with them)
+extern "C" int ddl_lin_fused_gram_ok(int C, int C2) {
+    LinFusedShape sh;
+    return lin_fused_shape(C, C2, sh) && sh.halves == 1;
+}
+
 extern "C" int ddl_lin_fused(const void* g, const void* z2, const void* b1, const void* q, const void* bias,
                              const void* y_prev, const void* fcoef, void* g2, void* stats, void* partial,
-                             long long M, int C, int C2, int nwg, hipStream_t stream) {
+                             void* gram, void* colsum, long long M, int C, int C2, int nwg, hipStream_t stream) {
     if (!g || !z2 || !b1 || !q || !bias || !g2 || !partial) return DDL_EINVAL;
+    if ((gram == nullptr) != (colsum == nullptr) || (gram && (!ddl_aligned16(gram) || !ddl_aligned16(colsum)))) return DDL_EINVAL;
+    if (gram && !ddl_lin_fused_gram_ok(C, C2)) return DDL_EINVAL;
     if ((y_prev == nullptr) != (fcoef == nullptr) || (y_prev == nullptr) != (stats == nullptr)) return DDL_EINVAL;
     if (nwg <= 0 || nwg != ddl_lin_fused_wgs(M, C, C2)) return DDL_EINVAL;
     const void* al[] = {g, z2, b1, q, bias, y_prev, fcoef, g2, stats, partial};
@@ -325,16 +394,19 @@ extern "C" int ddl_lin_fused(const void* g, const void* z2, const void* b1, cons
     p.g = (const bf16_t*)g; p.z2 = (const bf16_t*)z2; p.b1 = (const bf16_t*)b1; p.q = (const bf16_t*)q;
     p.bias = (const float*)bias; p.y_prev = (const bf16_t*)y_prev; p.fcoef = (const float*)fcoef;
     p.g2 = (bf16_t*)g2; p.stats = (float*)stats; p.partial = (float*)partial;
+    p.gram = (float*)gram; p.colsum = (float*)colsum;
     p.M = (int)M; p.ranges = nwg;
     const long long tiles = M / sh.BM;
     p.tiles_per_wg = (int)((tiles + nwg - 1) / nwg);
     const dim3 grid(nwg * sh.halves), block(512);
-    if (sh.halves == 1) {
-        if (y_prev) DDL_KLAUNCH((lin_fused_kernel<256, 64, 64, 1, true>), grid, block, 0, stream, p);
-        else DDL_KLAUNCH((lin_fused_kernel<256, 64, 64, 1, false>), grid, block, 0, stream, p);
-    } else {
-        if (y_prev) DDL_KLAUNCH((lin_fused_kernel<512, 128, 32, 2, true>), grid, block, 0, stream, p);
-        else DDL_KLAUNCH((lin_fused_kernel<512, 128, 32, 2, false>), grid, block, 0, stream, p);
-    }
+#define LF(CC, KK, BB, HH) do { \
+        if (y_prev) { if (gram) DDL_KLAUNCH((lin_fused_kernel<CC, KK, BB, HH, true, true>), grid, block, 0, stream, p); \
+                      else DDL_KLAUNCH((lin_fused_kernel<CC, KK, BB, HH, true, false>), grid, block, 0, stream, p); } \
+        else { if (gram) DDL_KLAUNCH((lin_fused_kernel<CC, KK, BB, HH, false, true>), grid, block, 0, stream, p); \
+               else DDL_KLAUNCH((lin_fused_kernel<CC, KK, BB, HH, false, false>), grid, block, 0, stream, p); } } while (0)
+    if (sh.halves == 1) LF(256, 64, 64, 1);
+    else if (y_prev) DDL_KLAUNCH((lin_fused_kernel<512, 128, 32, 2, true, false>), grid, block, 0, stream, p);
+    else DDL_KLAUNCH((lin_fused_kernel<512, 128, 32, 2, false, false>), grid, block, 0, stream, p);
+#undef LF
     return ddl_launch_status();
 }

@@ -847,7 +847,11 @@ def _lin_ds_static_ok(wd, ds_stride, x):
 
 # the input gradient and the raw weight-gradient product g^T z2 of a linear unit in ONE pass over g
 # (csrc/kernels/lin_fused.hip; DDL_LIN_FUSED=0: the two-segment GEMM + a separate weight-gradient launch)
-_LIN_FUSED = {"on": _os.environ.get("DDL_LIN_FUSED", "1") != "0"}
+# "gram" (DDL_LIN_FUSED_GRAM=1): the fused kernel also accumulates z2^T z2 and the column sums of z2 (stage 1), which
+# removes the Gram launch from the weight-gradient stream: 0.4 GB of traffic and four launches less per step, step time
+# EQUAL (16.17 / 16.16 ms: that launch ran in the shadow of the chain) - off by default, the longer-serving path stays.
+_LIN_FUSED = {"on": _os.environ.get("DDL_LIN_FUSED", "1") != "0",
+              "gram": _os.environ.get("DDL_LIN_FUSED_GRAM", "0") == "1"}
 
 
 def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev, fuse=None):
@@ -886,8 +890,13 @@ def _bn3_linear_dgrad(g, z2, w, coef_t, y_prev, fcoef_prev, fuse=None):
             tuple(z2.shape[2:]) == (H, W) and (y_prev is None or y_prev.stride() == z2.stride()):
         partial = None if y_prev is None else torch.empty((nwg, 2, C2), dtype=torch.float32, device=dev)
         P = torch.empty((nwg, C * C2), dtype=torch.float32, device=dev)
-        K.lin_fused(g, z2, b1, q, bias, y_prev, fcoef_prev, g2, partial, P, M, C, C2, nwg)
-        fuse["P"], fuse["splits"] = P, nwg
+        G = ZS = None
+        if fuse.get("want_gram") and _LIN_FUSED["gram"] and K.lin_fused_gram_ok(C, C2):
+            # the forward-data part of the weight gradient (z2^T z2, column sums of z2) from the same z2 tiles
+            G = torch.empty((nwg, C2 * C2), dtype=torch.float32, device=dev)
+            ZS = torch.empty((nwg, 2, C2), dtype=torch.float32, device=dev)
+        K.lin_fused(g, z2, b1, q, bias, y_prev, fcoef_prev, g2, partial, P, M, C, C2, nwg, gram=G, colsum=ZS)
+        fuse["P"], fuse["splits"], fuse["G"], fuse["ZS"] = P, nwg, G, ZS
         return g2, partial
     if y_prev is None:   # plain store (projection shortcut: the result is the addend of the block-input gradient)
         K.conv_igemm(g, _geom(g), b1, g2, C2, 1, 1, 1, 0, 0, 1, H, W, x2=z2, w2=q, c2=C2, bias=bias)
@@ -906,7 +915,7 @@ def _lin_gram_layout(M, C, C2):
     return rows, Tz, s2
 
 
-def _bn3_linear_gram(z2, w, raw, base, t, colz):
+def _bn3_linear_gram(z2, w, raw, base, t, colz, slabs=None):
     """The part of the linear weight gradient that only depends on FORWARD data: column sums of z2,
     the centred Gram matrix z2^T z2 - colz (x) colz / M and T = W (that matrix), written to the raw
     addresses ``colz`` ([2][C2] fp32) and ``t`` ([C][C2] bf16); ``base`` = scratch on stream ``raw``."""
@@ -919,6 +928,14 @@ def _bn3_linear_gram(z2, w, raw, base, t, colz):
     gp = base
     gram = gp + (4 * s2 * gslab + 255) // 256 * 256
     zp = gram + (2 * gslab + 255) // 256 * 256
+    if slabs is not None:
+        # (G, ZS, n): the Gram slabs and column sums came out of the fused input-gradient kernel
+        G, ZS, n = slabs
+        K.bn_colsum_fold(ZS, n, C2, colz, stream=raw)
+        K.splitk_reduce_centered(G, gram, C2, n, colz, M, stream=raw)
+        K.conv_igemm(w, (C, 1, 1, C2, C2, C2, C2, w.numel()), gram, _RawOut(t, C * C2), C2, 1, 1, 1, 0, 0, 1, 1, 1,
+                     stream=raw, w_numel=gslab)
+        return
     if K.conv_wgrad_colsum_ok(M, C2, C2):
         # the Gram launch sums the columns of z2 on the side (a row of ones through the matrix pipe): no extra pass over z2
         K.conv_wgrad(z2, z2, gz, gp, C2, 1, 1, 1, 0, 0, H, W, s2, stream=raw, colsum=zp)
@@ -980,6 +997,7 @@ def _bn3_linear_wgrad_start(g, z2, w, prewaited=False, pre=None, raw_product=Non
     B, _, H, W = g.shape
     M = B * H * W
     rawP = raw_product["P"] if raw_product else None
+    rawG = raw_product.get("G") if raw_product else None
     splits = raw_product["splits"] if rawP is not None else K.conv_wgrad_splits(M, C, C2, 1, 1)      # raw product g^T z2
     slab = C * C2
     pbytes = 0 if rawP is not None else (4 * splits * slab + 255) // 256 * 256
@@ -991,7 +1009,7 @@ def _bn3_linear_wgrad_start(g, z2, w, prewaited=False, pre=None, raw_product=Non
         base, raw = ws_t.data_ptr(), None
     else:
         raw = side.cuda_stream
-        if not prewaited:
+        if not prewaited or rawG is not None:      # (the Gram slabs are written by the main stream's fused kernel)
             K.stream_wait_stream(raw, K._raw_stream(), _SIDE["event"])
         base = _side_workspace(total)
     if rawP is not None:
@@ -1005,7 +1023,10 @@ def _bn3_linear_wgrad_start(g, z2, w, prewaited=False, pre=None, raw_product=Non
     else:
         t = base + pbytes
         colz = t + tbytes
-        _bn3_linear_gram(z2, w, raw, colz + 8 * C2, t, colz)   # (8*C2 bytes of column sums; C2 % 64 == 0 keeps the alignment)
+        _bn3_linear_gram(z2, w, raw, colz + 8 * C2, t, colz,   # (8*C2 bytes of column sums; C2 % 64 == 0 keeps the alignment)
+                         slabs=(rawG, raw_product["ZS"], raw_product["splits"]) if rawG is not None else None)
+    if rawG is not None:
+        rawP = (rawP, rawG, raw_product["ZS"])       # everything the side stream reads from main-stream tensors
     return (g, z2, w, pre, direct, out, side, raw, partial, slab, splits, t, colz, C, C2, ws_t, rawP)
 
 
@@ -1025,7 +1046,8 @@ def _bn3_linear_wgrad_finish(state, coef_t, coeffs, coef_late=False):
         if _SIDE["join_queued"]:
             _SIDE["keep"].append((g, z2, coef_t, coeffs, pre, rawP))
         else:
-            for t_ in (g, z2, coef_t, coeffs) + ((pre,) if pre is not None else ()) + ((rawP,) if rawP is not None else ()):
+            extra = () if rawP is None else (rawP if isinstance(rawP, tuple) else (rawP,))
+            for t_ in (g, z2, coef_t, coeffs) + ((pre,) if pre is not None else ()) + extra:
                 t_.record_stream(side)
     if direct:
         _notify(w)
@@ -1509,12 +1531,13 @@ class ResidualBlockFn(Function):
                 # the dependent chain first (the host is what the main stream waits for in the late
                 # layers: issuing the side-stream work first left 40-140 us holes in front of the prep kernel)
                 pre = early or _side_prewait(dz.device)   # the side stream may start before the chain's next kernels finish
-                lf = {} if wstate is None else None      # (the raw product may ride in the input-gradient kernel)
+                # (the raw product - and the Gram part, unless the forward pass did it - may ride in the input-gradient kernel)
+                lf = {"want_gram": getattr(ctx, "lin_pre", None) is None} if wstate is None else None
                 dz, fused = _bn3_linear_dgrad(g_short, inp, w, coef_t, ys[i - 1],
                                               cs[i - 1].data_ptr() + 8 * inp.shape[1], fuse=lf)
                 if wstate is None:
                     wstate = _bn3_linear_wgrad_start(g_short, inp, w, prewaited=pre, pre=getattr(ctx, "lin_pre", None),
-                                                     raw_product=lf if lf else None)
+                                                     raw_product=lf if (lf and "P" in lf) else None)
                 dw = _bn3_linear_wgrad_finish(wstate, coef_t, cs[i], coef_late=bool(early))
                 put(i, dw, dg, db)
                 _flush_notifications()
@@ -1570,11 +1593,11 @@ class ResidualBlockFn(Function):
                             xs = x if ds_stride == 1 else K.subsample2(x)
                         coef_d, dgd, dbd = _unit_coef(g_short, yd, gd, bd, cd, fused_ds)
                         pre = _side_prewait(g_short.device)
-                        lfd = {}
+                        lfd = {"want_gram": getattr(ctx, "lin_pre_ds", None) is None}
                         addend, _ = _bn3_linear_dgrad(g_short, xs, wd, coef_d, None, None, fuse=lfd)
                         sub2 = ds_stride == 2
                         dwd = _bn3_linear_wgrad(g_short, xs, wd, coef_d, cd, prewaited=pre,
-                                                pre=getattr(ctx, "lin_pre_ds", None), raw_product=lfd if lfd else None)
+                                                pre=getattr(ctx, "lin_pre_ds", None), raw_product=lfd if "P" in lfd else None)
                         put(units, dwd, dgd, dbd)
                     else:
                         dyd, dgd, dbd, _ = _unit_bwd(g_short, yd, None, gd, bd, cd, 0, False,

@@ -467,12 +467,20 @@ def lin_fused_wgs(M, C, C2):
     return int(lib().ddl_lin_fused_wgs(_i64(M), _i32(C), _i32(C2)))
 
 
-def lin_fused(g, z2, b1, q, bias, y_prev, fcoef, g2, stats, partial, M, C, C2, nwg, stream=None):
+@functools.lru_cache(maxsize=None)
+def lin_fused_gram_ok(C, C2):
+    """True when :func:`lin_fused` of this shape can also accumulate z2^T z2 and the column sums of z2."""
+    return bool(lib().ddl_lin_fused_gram_ok(_i32(C), _i32(C2)))
+
+
+def lin_fused(g, z2, b1, q, bias, y_prev, fcoef, g2, stats, partial, M, C, C2, nwg, stream=None, gram=None, colsum=None):
     """One pass over g [M][C] and z2 [M][C2]: g2 = mask(g b1^T + z2 q^T + bias) (masked by relu'(bn(y_prev)), with
-    the sums sum g2 | sum g2*y_prev in ``stats`` [nwg][2][C2]) and the slabs of g^T z2 in ``partial`` [nwg][C][C2]."""
-    f = _fn("ddl_lin_fused", "pppppppppp qiii p")
+    the sums sum g2 | sum g2*y_prev in ``stats`` [nwg][2][C2]) and the slabs of g^T z2 in ``partial`` [nwg][C][C2];
+    with ``gram`` [nwg][C2][C2] + ``colsum`` [nwg][2][C2] (where :func:`lin_fused_gram_ok`) also the slabs of z2^T z2
+    and the column sums of z2 (both rows of a slab's table alike)."""
+    f = _fn("ddl_lin_fused", "pppppppppp pp qiii p")
     check(f(_p(g), _p(z2), _p(b1), _p(q), _p(bias), _p(y_prev), _p(fcoef), _p(g2), _p(stats), _p(partial),
-            M, C, C2, nwg, _raw_stream() if stream is None else stream), "lin_fused")
+            _p(gram), _p(colsum), M, C, C2, nwg, _raw_stream() if stream is None else stream), "lin_fused")
 
 
 def splitk_reduce_centered(partial, out, C, splits, colz, M, stream=None):

@@ -1496,6 +1496,17 @@ def test_lin_fused_kernel_against_the_two_kernels_it_replaces(shape):
     Pp = torch.full((nwg, C * C2), float("nan"), device=DEV)
     K.lin_fused(g, z2, b1, q, bias, None, None, g2p, None, Pp, M, C, C2, nwg)
     assert torch.equal(g2p, g2p_ref) and torch.equal(Pp, P)
+    # the Gram matrix and the column sums of z2 from the same tiles (where the shape has the registers for it)
+    if K.lin_fused_gram_ok(C, C2):
+        G = torch.full((nwg, C2 * C2), float("nan"), device=DEV)
+        ZS = torch.full((nwg, 2, C2), float("nan"), device=DEV)
+        g2g = torch.empty_like(z2)
+        Pg = torch.empty_like(P)
+        stg = torch.empty_like(st)
+        K.lin_fused(g, z2, b1, q, bias, y_prev, fco, g2g, stg, Pg, M, C, C2, nwg, gram=G, colsum=ZS)
+        assert torch.equal(g2g, g2) and torch.equal(Pg, P) and torch.equal(stg, st)
+        assert rms_relerr(G.sum(0).view(C2, C2), zm.t() @ zm) < 1e-4
+        assert torch.allclose(ZS.sum(0)[0], zm.sum(0), rtol=1e-4, atol=1e-2) and torch.equal(ZS[:, 0], ZS[:, 1])
     # deterministic
     P2 = torch.empty_like(P)
     st2 = torch.empty_like(st)
@@ -1538,19 +1549,19 @@ def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form(stage):
         used["n"] += 1
         return real(*a, **k)
 
-    def run(on):
+    def run(on, gram=False):
         hip.reset_caches()
         ms = make()
         x = x0.detach().clone().requires_grad_(True)
-        saved = hip._LIN_FUSED["on"]
-        hip._LIN_FUSED["on"] = on
+        saved = hip._LIN_FUSED["on"], hip._LIN_FUSED["gram"]
+        hip._LIN_FUSED["on"], hip._LIN_FUSED["gram"] = on, gram
         K.lin_fused = counting
         try:
             out = ops.residual_chain(x, [_block_spec(m.pairs(), m.downsample) for m in ms], True, 0.1, 1e-5)
             out.backward(gout)
             torch.cuda.synchronize()
         finally:
-            hip._LIN_FUSED["on"] = saved
+            hip._LIN_FUSED["on"], hip._LIN_FUSED["gram"] = saved
             K.lin_fused = real
         names = [n for m in ms for n, _ in m.named_parameters()]
         return x.grad, names, [p.grad.float().clone() for m in ms for p in m.parameters()]
@@ -1563,3 +1574,8 @@ def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form(stage):
     assert rms_relerr(dx_a, dx_b) < 2e-3
     for n, a, b in zip(names, g_a, g_b):
         assert rms_relerr(a, b) < 5e-3, (n, rms_relerr(a, b))
+    if stage == 1:      # ... and with the Gram matrix / column sums from the same kernel (DDL_LIN_FUSED_GRAM=1)
+        dx_c, _, g_c = run(True, gram=True)
+        assert torch.equal(dx_c, dx_a)
+        for n, a, c in zip(names, g_a, g_c):
+            assert rms_relerr(c, a) < 5e-3, (n, rms_relerr(c, a))
