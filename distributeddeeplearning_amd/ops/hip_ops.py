@@ -424,6 +424,9 @@ def _conv_dgrad_1x1s2_compact(dy, w):
     return out
 
 
+_PROBE_NO_PREWAIT = _os_rows.environ.get("DDL_PROBE_NO_PREWAIT", "0") == "1"
+
+
 def _side_prewait(device):
     """Order the weight-gradient stream behind what is queued on the current stream NOW and return
     True, so that the weight-gradient kernels themselves can be issued later (after the next kernel
@@ -431,6 +434,8 @@ def _side_prewait(device):
     if not (_SIDE["on"] and _SIDE_LEAN and _DIRECT["on"] and _grad_listeners is not None):
         return False
     side = _side_stream(device)
+    if _PROBE_NO_PREWAIT:   # timing-only probe (results are wrong): what the event records on the main stream cost
+        return True
     K.stream_wait_stream(side.cuda_stream, K._raw_stream(), _SIDE["event"])
     return True
 

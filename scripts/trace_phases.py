@@ -23,9 +23,15 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     for r in rows:
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    sgd = [i for i, r in enumerate(rows) if "fused_sgd" in r["Kernel_Name"] or "fused_lars" in r["Kernel_Name"]]
-    ends = [i for k, i in enumerate(sgd) if k + 1 == len(sgd) or rows[sgd[k + 1]]["s"] - rows[i]["e"] > 2e6]
-    win = rows[ends[-2] + 1: ends[-1] + 1]
+    # a step = from one loader gather to the next (with early bucket updates the optimizer kernels are spread over
+    # backward, so they no longer delimit steps); without a device loader: the old rule (gaps after the optimizer)
+    gath = [i for i, r in enumerate(rows) if "pool_gather_kernel" in r["Kernel_Name"]]
+    if len(gath) >= 3:
+        win = rows[gath[-2]: gath[-1]]
+    else:
+        sgd = [i for i, r in enumerate(rows) if "fused_sgd" in r["Kernel_Name"] or "fused_lars" in r["Kernel_Name"]]
+        ends = [i for k, i in enumerate(sgd) if k + 1 == len(sgd) or rows[sgd[k + 1]]["s"] - rows[i]["e"] > 2e6]
+        win = rows[ends[-2] + 1: ends[-1] + 1]
     t0 = win[0]["s"]
     byq = collections.defaultdict(list)
     for r in win:
@@ -33,9 +39,11 @@ def main():
     mainq = max(byq, key=lambda k: len(byq[k]))
     main_rows = byq[mainq]
     side_rows = [r for q, l in byq.items() if q != mainq for r in l]
-    xent = next(r for r in main_rows if "softmax_xent" in r["Kernel_Name"])
-    first_sgd = next(r for r in main_rows if "fused_sgd" in r["Kernel_Name"] or "fused_lars" in r["Kernel_Name"])
-    phases = [("forward", t0, xent["e"]), ("backward", xent["e"], first_sgd["s"]), ("update", first_sgd["s"], win[-1]["e"])]
+    xent = next(r for r in main_rows if "xent" in r["Kernel_Name"] or "cross_entropy" in r["Kernel_Name"])
+    upd = [r for r in main_rows if "fused_sgd" in r["Kernel_Name"] or "fused_lars" in r["Kernel_Name"]]
+    last_bwd = max((r for r in main_rows if "conv_" in r["Kernel_Name"] or "stem_" in r["Kernel_Name"]), key=lambda r: r["e"])
+    first_sgd = next((r for r in upd if r["s"] >= last_bwd["e"]), win[-1])
+    phases = [("forward", t0, xent["e"]), ("backward", xent["e"], first_sgd["s"]), ("update", first_sgd["s"], max(r["e"] for r in win))]
     print("last step %.3f ms, %d kernels (%d main stream, %d other streams)" % (
         (win[-1]["e"] - t0) / 1e6, len(win), len(main_rows), len(side_rows)))
     if len(sys.argv) > 2 and sys.argv[2] == "--list":   # every kernel of the step in start order
