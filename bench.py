@@ -83,6 +83,13 @@ _T_START = time.perf_counter()
 
 def main(argv=None):
     args = parse_args(argv)
+    # DDL_BENCH_WATCHDOG=<seconds>: every thread's Python stack goes to stderr if the run is still alive after that
+    # long (repeated): a hang in start-up, in a collective or in a step names itself instead of just timing out
+    wd = float(os.environ.get("DDL_BENCH_WATCHDOG", "0") or 0)
+    if wd > 0:
+        import faulthandler
+
+        faulthandler.dump_traceback_later(wd, repeat=True, exit=False)
     use_cuda = (args.device or ("cuda" if torch.cuda.is_available() else "cpu")) == "cuda"
     hvd.init()
     world, rank = hvd.size(), hvd.rank()
