@@ -533,7 +533,17 @@ def _side_stream(device):
     if st is None or st.device != device:
         import os
 
-        prio = os.environ.get("DDL_WGRAD_STREAM_PRIORITY", "low")
+        prio = os.environ.get("DDL_WGRAD_STREAM_PRIORITY")
+        if prio is None:
+            # Several ranks on ONE device (rehearsal rigs; never the production layout): a low-priority queue of one
+            # process can be starved for ever by a normal-priority queue of ANOTHER process that sits on a wait which
+            # only this process can end (priority inversion across processes - seen as an intermittent hang of the
+            # two-rank gloo rehearsal with the GPU 100 % busy, profiles/r3_notes.md section 28): normal priority there
+            try:
+                shared = int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > max(torch.cuda.device_count(), 1)
+            except ValueError:
+                shared = False
+            prio = "0" if shared else "low"
         if prio == "torch":
             st = torch.cuda.Stream(device=device)
         else:
