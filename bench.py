@@ -85,7 +85,8 @@ def main(argv=None):
     args = parse_args(argv)
     # DDL_BENCH_WATCHDOG=<seconds>: every thread's Python stack goes to stderr if the run is still alive after that
     # long (repeated): a hang in start-up, in a collective or in a step names itself instead of just timing out
-    wd = float(os.environ.get("DDL_BENCH_WATCHDOG", "0") or 0)
+    # (several ranks: on by default - the first run on a multi-GPU node has to explain itself if it stalls)
+    wd = float(os.environ.get("DDL_BENCH_WATCHDOG", "180" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "0") or 0)
     if wd > 0:
         import faulthandler
 
