@@ -365,7 +365,14 @@ extern "C" int ddl_stream_priority_range(int* least, int* greatest) {
 // record that preceded it, later records do not disturb it.
 extern "C" int ddl_event_create(void** out) {
     hipEvent_t e = nullptr;
-    if (!out || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DDL_ELAUNCH;
+    // DDL_EVENT_FLAGS (experiment, profiles/r3_notes.md section 29): 1 = device-scope release when the event is recorded
+    // (16.20 -> 16.18 ms), 2 = no system-scope fences (16.20 -> 16.13 ms, bit-identical over 6 800 single-process steps - but
+    // the two-rank xGMI rig then times out in its first gradient collective: peers no longer see the data).  Default 0.
+    static const int mode = getenv("DDL_EVENT_FLAGS") ? atoi(getenv("DDL_EVENT_FLAGS")) : 0;  // tuning knob
+    unsigned flags = hipEventDisableTiming;
+    if (mode == 1) flags |= hipEventReleaseToDevice;
+    if (mode == 2) flags |= hipEventDisableSystemFence;
+    if (!out || hipEventCreateWithFlags(&e, flags) != hipSuccess) return DDL_ELAUNCH;
     *out = (void*)e;
     return DDL_OK;
 }
