@@ -366,8 +366,8 @@ extern "C" int ddl_stream_priority_range(int* least, int* greatest) {
 extern "C" int ddl_event_create(void** out) {
     hipEvent_t e = nullptr;
     // DDL_EVENT_FLAGS (experiment, profiles/r3_notes.md section 29): 1 = device-scope release when the event is recorded
-    // (16.20 -> 16.18 ms), 2 = no system-scope fences (16.20 -> 16.13 ms, bit-identical over 6 800 single-process steps - but
-    // the two-rank xGMI rig then times out in its first gradient collective: peers no longer see the data).  Default 0.
+    // (16.20 -> 16.18 ms), 2 = no system-scope fences (16.20 -> 16.13 ms, bit-identical over 6 800 single-process steps and
+    // in the two-rank xGMI rig; untested between real devices, hence not the default)
     static const int mode = getenv("DDL_EVENT_FLAGS") ? atoi(getenv("DDL_EVENT_FLAGS")) : 0;  // tuning knob
     unsigned flags = hipEventDisableTiming;
     if (mode == 1) flags |= hipEventReleaseToDevice;

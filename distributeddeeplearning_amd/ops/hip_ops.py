@@ -535,12 +535,15 @@ def _side_stream(device):
 
         prio = os.environ.get("DDL_WGRAD_STREAM_PRIORITY")
         if prio is None:
-            # Several ranks on ONE device (rehearsal rigs; never the production layout): a low-priority queue of one
-            # process can be starved for ever by a normal-priority queue of ANOTHER process that sits on a wait which
-            # only this process can end (priority inversion across processes - seen as an intermittent hang of the
-            # two-rank gloo rehearsal with the GPU 100 % busy, profiles/r3_notes.md section 28): normal priority there
+            # Several ranks on ONE device over the HOST backend (gloo rehearsal rig; never the production layout): a
+            # low-priority queue of one process can be starved for ever by a normal-priority queue of ANOTHER process that
+            # sits on a wait which only this process can end (priority inversion across processes - an intermittent hang of
+            # the two-rank gloo rehearsal with the GPU 100 % busy, profiles/r3_notes.md section 28): normal priority there.
+            # (The two-rank xGMI rig needs the opposite: its resident collective kernels run at low priority, and a
+            # normal-priority weight-gradient stream next to them stalls the exchange - it keeps `low`.)
             try:
-                shared = int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > max(torch.cuda.device_count(), 1)
+                shared = int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > max(torch.cuda.device_count(), 1) and \
+                    os.environ.get("HVD_BACKEND", "") == "gloo"
             except ValueError:
                 shared = False
             prio = "0" if shared else "low"
