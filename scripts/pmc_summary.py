@@ -12,7 +12,7 @@ import os
 import re
 import sys
 
-OURS = ("conv_igemm_kernel", "conv_wgrad", "conv_rows", "splitk_reduce", "pool_gather", "subsample2", "bump_counters", "stem_", "lars_", "bn_", "maxpool", "label_rank", "segmented_sqnorms", "nchw_to_nhwc", "colsum", "bias_add", "stem_pool",
+OURS = ("conv_igemm_kernel", "conv_wgrad", "lin_fused", "gemm256", "step_aux", "bn_lin", "conv_rows", "splitk_reduce", "pool_gather", "subsample2", "bump_counters", "stem_", "lars_", "bn_", "maxpool", "label_rank", "segmented_sqnorms", "nchw_to_nhwc", "colsum", "bias_add", "stem_pool",
         "avgpool", "softmax_xent", "fused_sgd", "fused_lars", "weight_flip", "stem_pack",
         "xgmi_allreduce", "pack_kernel", "philox")
 
