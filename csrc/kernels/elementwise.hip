@@ -365,10 +365,13 @@ extern "C" int ddl_stream_priority_range(int* least, int* greatest) {
 // record that preceded it, later records do not disturb it.
 extern "C" int ddl_event_create(void** out) {
     hipEvent_t e = nullptr;
-    // DDL_EVENT_FLAGS (experiment, profiles/r3_notes.md section 29): 1 = device-scope release when the event is recorded
+    // DDL_EVENT_FLAGS (profiles/r3_notes.md section 29): 0 = plain events, 1 = device-scope release when the event is recorded
     // (16.20 -> 16.18 ms), 2 = no system-scope fences (16.20 -> 16.13 ms, bit-identical over 6 800 single-process steps and
-    // in the two-rank xGMI rig; untested between real devices, hence not the default)
-    static const int mode = getenv("DDL_EVENT_FLAGS") ? atoi(getenv("DDL_EVENT_FLAGS")) : 0;  // tuning knob
+    // in the two-rank xGMI rig).  These events only order the two streams of ONE device; what leaves the device passes an
+    // event of the engine (csrc/engine, plain flags) first.  Default: 2 in a one-process job, 0 when WORLD_SIZE > 1 -
+    // nothing between real devices could be tested.
+    static const int mode = getenv("DDL_EVENT_FLAGS") ? atoi(getenv("DDL_EVENT_FLAGS"))
+                          : (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 ? 0 : 2);
     unsigned flags = hipEventDisableTiming;
     if (mode == 1) flags |= hipEventReleaseToDevice;
     if (mode == 2) flags |= hipEventDisableSystemFence;
