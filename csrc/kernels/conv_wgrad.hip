@@ -1210,7 +1210,10 @@ extern "C" int ddl_conv_wgrad_ex3(const void* dy, const void* x, void* partial, 
         p.tiles_k = K / 256;
         p.tiles_rsc = R * S * C / 256;
         dim3 grid(p.tiles_k * p.tiles_rsc * p.splits), block(512);
-        static const int pipe = getenv("DDL_WGRAD_BIG_PIPE") ? atoi(getenv("DDL_WGRAD_BIG_PIPE")) : 0;  // tuning knob
+        // fragments of tile t+1 read under the MFMAs of tile t: +2-3 % alone; nothing in the step while the weight-gradient
+        // stream had slack (17.70 / 17.73 vs 17.68 / 17.70), -0.12 ms now that both streams are critical (16.27 / 16.29 /
+        // 16.24 -> 16.15 / 16.12 / 16.14, profiles/r3_notes.md section 31); same bits
+        static const int pipe = getenv("DDL_WGRAD_BIG_PIPE") ? atoi(getenv("DDL_WGRAD_BIG_PIPE")) : 1;  // tuning knob
 #define BIGL(SIMP, N, P) DDL_KLAUNCH((conv_wgrad256_kernel<SIMP, N, P>), grid, block, 0, stream, p)
         if (colsum) {
             DDL_KLAUNCH((conv_wgrad256_kernel<true, 3, false, true>), grid, block, 0, stream, p);

@@ -1579,3 +1579,45 @@ def test_linear_units_with_the_fused_kernel_match_the_two_kernel_form(stage):
         assert torch.equal(dx_c, dx_a)
         for n, a, c in zip(names, g_a, g_c):
             assert rms_relerr(c, a) < 5e-3, (n, rms_relerr(c, a))
+
+
+_WGRAD_BIG_SNIPPET = r"""
+import torch
+from distributeddeeplearning_amd.ops import hip_ops as hip
+def wide_weight_gradients():
+    out = []
+    for (B, C, K, hw, r) in ((64, 1024, 256, 14, 1), (64, 256, 256, 14, 3), (32, 512, 2048, 7, 1)):
+        g = torch.Generator().manual_seed(100 + C + K + r)
+        x = torch.randn(B, C, hw, hw, generator=g).to("cuda", torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(B, K, hw, hw, generator=g).to("cuda", torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = torch.zeros(K, C, r, r, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        out.append((hip._conv_wgrad(dy, x, w, 1, r // 2).float().cpu(), x.float().cpu(), dy.float().cpu(), r))
+    torch.cuda.synchronize()
+    return out
+"""
+
+
+def test_both_loop_forms_of_the_wide_weight_gradient_kernel_give_the_same_bits(tmp_path):
+    """``conv_wgrad256_kernel`` with the next tile's fragments read under the current tile's MFMAs
+    (``DDL_WGRAD_BIG_PIPE=1``, the default) and its plain loop (``=0``, in a child process: the switch is read once)
+    accumulate in the same order: equal bits; and both match an fp32 convolution gradient."""
+    import os
+    import subprocess
+    import sys
+
+    ns = {}
+    exec(_WGRAD_BIG_SNIPPET, ns)
+    here = ns["wide_weight_gradients"]()
+    for dw, x, dy, r in here:
+        ref = torch.nn.grad.conv2d_weight(x, dw.shape, dy, stride=1, padding=r // 2)
+        err = (dw - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-2, err
+    path = str(tmp_path / "plain.pt")
+    code = _WGRAD_BIG_SNIPPET + "\ntorch.save([t[0] for t in wide_weight_gradients()], %r)\nprint('OK')\n" % path
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DDL_WGRAD_BIG_PIPE="0", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-3000:]
+    plain = torch.load(path, weights_only=True)
+    for (dw, _, _, _), other in zip(here, plain):
+        assert torch.equal(dw, other)
