@@ -356,15 +356,20 @@ static bool lin_fused_shape(int C, int C2, LinFusedShape& s) {
 }  // namespace
 
 // Pixel ranges (= slabs of the raw product = statistics rows) the fused kernel uses for M pixels; 0 = not served
-// (DDL_LIN_FUSED=0 switches it off, 1 = stage 1 only; DDL_LIN_FUSED_WGS = ranges to aim for, one per CU by default)
+// (DDL_LIN_FUSED=0 switches it off, 1 = stage 1 only; DDL_LIN_FUSED_WGS / _WGS2 = ranges to aim for in the one- / two-workgroup form)
 extern "C" int ddl_lin_fused_wgs(long long M, int C, int C2) {
     static const int on = getenv("DDL_LIN_FUSED") ? atoi(getenv("DDL_LIN_FUSED")) : 2;         // tuning knob
-    static const int wgs = getenv("DDL_LIN_FUSED_WGS") ? atoi(getenv("DDL_LIN_FUSED_WGS")) : 256;  // tuning knob
+    // 128 ranges: half the CUs for this launch, the other half for the weight-gradient stream's kernels, which aim for 128
+    // workgroups too (16.01 / 16.02 / 16.03 ms with 256 -> 15.94 / 15.93 / 15.95; 96 / 160 / 192: 16.13 / 16.15 / 16.03 -
+    // profiles/r3_notes.md section 32); the two-workgroup form of stage 2 then runs 256 workgroups, one round
+    static const int wgs1 = getenv("DDL_LIN_FUSED_WGS") ? atoi(getenv("DDL_LIN_FUSED_WGS")) : 128;  // tuning knob
+    static const int wgs2 = getenv("DDL_LIN_FUSED_WGS2") ? atoi(getenv("DDL_LIN_FUSED_WGS2")) : wgs1;  // tuning knob (ranges of the two-workgroup form)
     LinFusedShape sh;
     if (!on || !lin_fused_shape(C, C2, sh) || (sh.halves == 2 && on < 2)) return 0;
     if (M <= 0 || M % sh.BM != 0 || M * C * 2 >= 0x7fffffffLL) return 0;
     const long long tiles = M / sh.BM;
     if (tiles < 512) return 0;                                  // small problems: the two plain kernels
+    const int wgs = sh.halves == 2 ? wgs2 : wgs1;
     const long long per = (tiles + wgs - 1) / wgs;
     long long ranges = (tiles + per - 1) / per;
     if (sh.halves == 2) ranges = (ranges + 7) / 8 * 8;          // (pairs of workgroups are dealt to the XCDs in groups of 8)
