@@ -1,6 +1,6 @@
 // Memory-bound support kernels: K19 Philox synthetic data, K14 fused
 // SGD-momentum-weight-decay over flat arenas, K15 fused LARS (segmented norms + update),
-// K16 is one hipMemsetAsync per gradient arena (ddl_memset_async in step_aux.hip), K20 NCHW fp32 -> NHWC bf16.
+// K16 is one fill launch per gradient arena (ddl_memset_async in step_aux.hip), K20 NCHW fp32 -> NHWC bf16.
 // All kernels: wave64, 256-thread blocks, 16-byte vector accesses, grid-stride.
 #include "common.h"
 

@@ -149,9 +149,28 @@ extern "C" int ddl_bump_counters(const void* table, int n, hipStream_t stream) {
     return ddl_launch_status();
 }
 
-// K16: zero a gradient arena (one fill dispatch; the reference's optimizer.zero_grad() issues 161)
+// K16: zero a gradient arena (one dispatch; the reference's optimizer.zero_grad() issues 161).  An own kernel rather
+// than hipMemsetAsync: the runtime's fill arrives with ~15 us of idle queue on either side of it (two arenas at the head
+// of every step: 58 us from the loader's gather to the stem's first kernel, ~16 us of it work - profiles/r3_notes.md
+// section 35); unaligned spans still go through the runtime.
+namespace {
+__global__ __launch_bounds__(256) void fill16_kernel(u32x4* __restrict__ p, long long nvec, uint32_t word) {
+    const u32x4 v = {word, word, word, word};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) p[i] = v;
+}
+}  // namespace
+
 extern "C" int ddl_memset_async(void* p, int value, long long bytes, hipStream_t stream) {
     if (!p || bytes <= 0) return DDL_EINVAL;
+    static const int own = getenv("DDL_FILL_KERNEL") ? atoi(getenv("DDL_FILL_KERNEL")) : 1;  // tuning knob
+    if (own && ddl_aligned16(p) && (bytes & 15) == 0) {
+        const long long nvec = bytes >> 4;
+        long long blocks = (nvec + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        const uint32_t b = (uint32_t)(value & 0xff), word = b | (b << 8) | (b << 16) | (b << 24);
+        DDL_KLAUNCH(fill16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (u32x4*)p, nvec, word);
+        return ddl_launch_status();
+    }
     if (hipMemsetAsync(p, value, (size_t)bytes, stream) != hipSuccess) return DDL_ELAUNCH;
     if (ddl::tape::recording()) ddl::tape::push([=]() { (void)hipMemsetAsync(p, value, (size_t)bytes, stream); });
     return DDL_OK;

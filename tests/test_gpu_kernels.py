@@ -1621,3 +1621,17 @@ def test_both_loop_forms_of_the_wide_weight_gradient_kernel_give_the_same_bits(t
     plain = torch.load(path, weights_only=True)
     for (dw, _, _, _), other in zip(here, plain):
         assert torch.equal(dw, other)
+
+
+@pytest.mark.parametrize("nbytes,value", [(16, 0), (4096 * 16 + 16, 0), (51_200_000, 0), (1 << 20, 0x5A), (1000, 0), (48 + 8, 7)])
+def test_arena_fill_kernel_and_its_runtime_fallback(nbytes, value):
+    """K16 (``ddl_memset_async``): 16-byte aligned spans are filled by the in-tree kernel, anything else by the
+    runtime's memset; neither touches a byte outside the span."""
+    from distributeddeeplearning_amd.ops import kernels as K
+
+    guard = 64
+    buf = torch.full((nbytes + 2 * guard,), 0xEE, dtype=torch.uint8, device=DEV)
+    K.memset_async(buf[guard:guard + nbytes], value)
+    torch.cuda.synchronize()
+    assert bool((buf[guard:guard + nbytes] == value).all())
+    assert bool((buf[:guard] == 0xEE).all()) and bool((buf[guard + nbytes:] == 0xEE).all())
