@@ -12,7 +12,7 @@ an update is **one launch per hyper-parameter run** — two for ResNet-50 (bf16 
 with weight decay, fp32 BatchNorm/bias without) — and the gradient arena doubles as the
 all-reduce buffer.  bf16 parameters are updated from fp32 masters (bf16 has 8 mantissa bits;
 ``lr·g`` would vanish against the weight otherwise) and the bf16 copy is rewritten in the
-same pass.  ``zero_grad`` is one memset per arena.
+same pass.  ``zero_grad`` is one fill launch per arena.
 
 Update rule (identical to ``torch.optim.SGD``): ``g' = g + wd·w``; ``v = μ·v + g'``;
 ``w = w − lr·(g' + μ·v if nesterov else v)``.
