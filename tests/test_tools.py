@@ -204,3 +204,67 @@ def test_flavour_images_point_at_real_scripts_and_known_settings():
                 continue
             assert '"%s"' % k in cfg_src, (name, k)
         assert "ddlrun" in text and "BASE_IMAGE" in text
+
+
+def test_pmc_step_traffic_sums_one_step_between_two_gathers(tmp_path):
+    """scripts/pmc_step_traffic.py: FETCH_SIZE + WRITE_SIZE (KiB) of the dispatches between the last two loader gathers."""
+    import subprocess
+    import sys
+
+    hdr = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id",
+           "Grid_Size", "Kernel_Id", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size",
+           "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name",
+           "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+
+    def rows(counter, per_kernel):
+        out, t = [], 0
+        for step in range(3):
+            for name, val in (("pool_gather_kernel", 1.0), ("conv_igemm_kernel<a>", per_kernel), ("bn_apply", per_kernel)):
+                out.append([1, len(out) + 1, "Agent 1", 1, 9, 9, 1024, 1, name, 256, 0, 0, 8, 0, 8, counter,
+                            val * (step + 1), t, t + 1000])
+                t += 2000
+        return out
+
+    _write_csv(str(tmp_path / "run" / "fetch" / "vm" / "1_counter_collection.csv"), hdr, rows("FETCH_SIZE", 1e6))
+    _write_csv(str(tmp_path / "run" / "write" / "vm" / "2_counter_collection.csv"), hdr, rows("WRITE_SIZE", 5e5))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_step_traffic.py"), str(tmp_path / "run")],
+                         capture_output=True, text=True, check=True).stdout
+    # the window is step 2 of 3 (values doubled): gather + two kernels
+    fetch = (2.0 + 2 * 2e6) * 1024 / 1e9
+    write = (2.0 + 2 * 1e6) * 1024 / 1e9
+    assert "%-11s %7.2f GB over 3 dispatches" % ("FETCH_SIZE", fetch) in out
+    assert "per step    %7.2f GB" % (fetch + write) in out
+
+
+def test_trace_phases_splits_a_step_into_forward_backward_and_streams(tmp_path):
+    """scripts/trace_phases.py: steps delimited by the loader gather, phases by the loss kernel, streams by queue."""
+    import subprocess
+    import sys
+
+    hdr = ["Kind", "Agent_Id", "Queue_Id", "Stream_Id", "Thread_Id", "Dispatch_Id", "Kernel_Id",
+           "Kernel_Name", "Correlation_Id", "Start_Timestamp", "End_Timestamp", "LDS_Block_Size",
+           "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X",
+           "Workgroup_Size_Y", "Workgroup_Size_Z", "Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"]
+
+    def row(q, s, name, a, b):
+        return ["KERNEL_DISPATCH", "Agent 1", q, s, 1, 1, 1, name, 1, a, b, 0, 0, 8, 0, 8, 256, 1, 1, 1024, 1, 1]
+
+    rows = []
+    for step in range(4):
+        base = step * 1_000_000
+        rows.append(row(1, 0, "pool_gather_kernel", base, base + 10_000))
+        rows.append(row(1, 0, "conv_igemm_kernel<1>", base + 10_000, base + 200_000))
+        rows.append(row(1, 0, "softmax_xent_kernel", base + 200_000, base + 210_000))
+        rows.append(row(1, 0, "conv_igemm_kernel<2>", base + 210_000, base + 350_000))
+        rows.append(row(1, 0, "bn_bwd_apply_kernel", base + 380_000, base + 500_000))         # 30 us gap
+        rows.append(row(2, 1, "conv_wgrad_kernel<a>", base + 250_000, base + 450_000))
+        rows.append(row(2, 1, "fused_sgd_kernel<true, true>", base + 450_000, base + 460_000))  # early update: not a delimiter
+        rows.append(row(1, 0, "fused_sgd_kernel<true, true>", base + 500_000, base + 520_000))
+    path = str(tmp_path / "1_kernel_trace.csv")
+    _write_csv(path, hdr, rows)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "trace_phases.py"), path],
+                         capture_output=True, text=True, check=True).stdout
+    assert "8 kernels (6 main stream, 2 other streams)" in out
+    assert "forward: 0.210 ms window" in out and "backward: 0.290 ms window" in out
+    assert "other streams 2 kernels busy 0.210 ms" in out
+    assert "gap   30.0 us" in out
