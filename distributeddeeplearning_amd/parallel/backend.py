@@ -183,6 +183,10 @@ def init(backend: str | None = None, timeout_s: float | None = None) -> None:
         _S.local_rank = int(lrk)
         _S.local_size = int(lsz) if lsz is not None else (min(world, n_dev) if n_dev else world)
         _S.rank, _S.size = rk, world
+        if world > 1:
+            # events between the two streams of a device keep their system-scope fences when several ranks run
+            # (csrc/kernels/elementwise.hip::ddl_event_create reads WORLD_SIZE itself; mpirun-style launchers export other names)
+            os.environ.setdefault("DDL_EVENT_FLAGS", "0")
 
         if want == "rccl":
             # Pin the device before the communicator exists: RCCL binds to the current device.
